@@ -1,0 +1,169 @@
+"""Pin oracle/dsp_oracle.py against fixtures produced by the real reference
+(tools/gen_golden.py, run in the build container).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_calls_equal, dense_calls, load_json, load_npz
+from oracle import dsp_oracle as O
+from rtldavis_amd import synth
+
+PROD = O.production_config()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_calls(dem, raw, complex_input=None):
+    B = dem.cfg.block_size
+    calls, bits = [], []
+    n = raw.size // 2 if complex_input is None else complex_input.size
+    for b in range(n // B):
+        blk = raw[2 * B * b: 2 * B * (b + 1)] if complex_input is None else complex_input[B * b: B * (b + 1)]
+        calls.append(dem.demodulate(blk))
+        bits.append(dem.quantized[dem.cfg.buffer_length - B:].copy())
+    return calls, np.concatenate(bits)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 17, 42, 63])
+def test_streams_mirror_and_oneshot(seed, golden_streams):
+    g = golden_streams[str(seed)]
+    raw = synth.synth_stream(seed)
+    assert sha(raw) == g["raw_sha256"], "synthetic generator drifted from the fixtures"
+    want = dense_calls(g["calls"], synth.BLOCKS_PER_STREAM)
+    calls, bits = run_calls(O.OracleDemodulator(PROD), raw)
+    assert sha(O.pack_bits_le(bits)) == g["bits_sha256"]
+    assert_calls_equal(calls, want)
+    f, d, bits1 = O.demod_stream_oneshot(raw)
+    assert sha(O.pack_bits_le(bits1)) == g["bits_sha256"]
+    assert_calls_equal(O.calls_from_oneshot(f, bits1, PROD), want)
+    # exactly one CRC-valid packet: the payload the stream carries
+    good = [p for c in calls for p in c
+            if O.crc16_ccitt(bytes(O.swap_bit_order(b) for b in p.data)[2:]) == 0]
+    assert [bytes(p.data).hex() for p in good] == [g["payload"]]
+
+
+def test_full_bits_seeds_0_3():
+    z = load_npz("streams_bits.npz")
+    for seed in range(4):
+        _, _, bits = O.demod_stream_oneshot(synth.synth_stream(seed))
+        assert np.array_equal(O.pack_bits_le(bits), z[f"seed{seed}"])
+
+
+def test_burst_cut_config1():
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    g = load_json("burst_seed0_b20_22.json")
+    st = load_npz("burst_seed0_b20_22_state.npz")
+    assert sha(raw) == g["raw_sha256"]
+    dem = O.OracleDemodulator(PROD)
+    calls, bits = run_calls(dem, raw)
+    assert_calls_equal(calls, g["calls"])
+    assert [bytes(p.data).hex() for c in calls for p in c][0] == "cb890520ac8bd4000e5c"
+    assert np.array_equal(O.pack_bits_le(bits), st["bits"])
+    assert np.array_equal(O.pack_bits_le(dem.quantized), st["quantized"])
+    np.testing.assert_allclose(dem.filtered, st["filtered"], rtol=0, atol=1e-14)
+    ref = st["discriminated"]
+    assert np.all(np.abs(dem.discriminated - ref) <= 1e-9 * np.maximum(1, np.abs(ref)))
+    # parse(): CRC gate and frequency error (protocol.py:297-311)
+    want = g["parse"][1][0]
+    pk = calls[1][0]
+    data = bytes(O.swap_bit_order(b) for b in pk.data)
+    assert O.crc16_ccitt(data[2:]) == 0 and (data[2] & 7) == want["id"]
+    # freq_err is read from the demodulator state of the call that returned the packet
+    dem2 = O.OracleDemodulator(PROD)
+    dem2.demodulate(raw[: 2 * 8192]); dem2.demodulate(raw[2 * 8192: 4 * 8192])
+    assert O.freq_error(dem2.discriminated, pk.index, PROD) == want["freq_err"] == -1356
+
+
+def test_default_block_512():
+    z = load_npz("b512_stages.npz")
+    g = load_json("b512_calls.json")
+    cfg = O.OracleConfig(**g["config"])
+    assert cfg.buffer_length == 2048
+    dem = O.OracleDemodulator(cfg)
+    calls, bits = run_calls(dem, z["raw"])
+    assert_calls_equal(calls, g["calls"])
+    assert np.array_equal(O.pack_bits_le(bits), z["bits"])
+    assert np.array_equal(dem.quantized, z["last_quantized"])
+    np.testing.assert_array_equal(dem.iq, z["last_iq"])  # LUT + rotation are exact
+    np.testing.assert_allclose(dem.filtered, z["last_filtered"], rtol=0, atol=1e-14)
+    ref = z["last_discriminated"]
+    assert np.all(np.abs(dem.discriminated - ref) <= 1e-9 * np.maximum(1, np.abs(ref)))
+    np.testing.assert_array_equal(O.byte_to_cmplx(z["raw"][-1024:]), z["last_raw_samples"])
+    f, d, bits1 = O.demod_stream_oneshot(z["raw"])
+    assert np.array_equal(O.pack_bits_le(bits1), z["bits"])
+    assert_calls_equal(O.calls_from_oneshot(f, bits1, cfg), g["calls"])
+
+
+def test_edge_q_equals_block_size():
+    g = load_json("edge_q_eq_B.json")
+    raw = synth.synth_stream(g["seed"], n_samples=g["n_samples"], start=g["start"])
+    assert sha(raw) == g["raw_sha256"]
+    calls, bits = run_calls(O.OracleDemodulator(PROD), raw)
+    assert_calls_equal(calls, g["calls"])
+    idx = [(b, p.index) for b, c in enumerate(calls) for p in c]
+    assert (2, 8192) in idx and (3, 0) in idx
+    f, d, bits1 = O.demod_stream_oneshot(raw)
+    assert_calls_equal(O.calls_from_oneshot(f, bits1, PROD), g["calls"])
+
+
+def test_alt_symbol_length_8():
+    g = load_json("alt_s8_b1024.json")
+    cfg = O.OracleConfig(**g["config"])
+    raw = synth.synth_stream(g["seed"], n_samples=g["n_samples"], symbol_length=8, margin=g["margin"])
+    assert sha(raw) == g["raw_sha256"]
+    calls, bits = run_calls(O.OracleDemodulator(cfg), raw)
+    assert_calls_equal(calls, g["calls"])
+    assert np.array_equal(O.pack_bits_le(bits), load_npz("alt_s8_b1024_bits.npz")["bits"])
+
+
+def test_complex_input_branch():
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    cplx = (raw[0::2].astype(np.float64) - 127.5) / 127.5 + 1j * (raw[1::2].astype(np.float64) - 127.5) / 127.5
+    g = load_json("complex_input.json")
+    st = load_npz("complex_input_state.npz")
+    dem = O.OracleDemodulator(PROD)
+    calls, bits = run_calls(dem, None, complex_input=cplx)
+    assert_calls_equal(calls, g["calls"])
+    assert np.array_equal(O.pack_bits_le(bits), st["bits"])
+    # phase-major order inside a call (dsp.py:175-186): 5502 (phase 0) before 536 (phase 4)
+    assert [p.index for p in calls[1]] == [5502, 536]
+
+
+def test_startup_signed_zero_quadrants():
+    g = load_json("startup_quadrants.json")
+    cfg = O.OracleConfig(block_size=512)
+    for name, rec in g.items():
+        raw = np.frombuffer(bytes.fromhex(rec["raw"]), dtype=np.uint8)
+        f, d, bits = O.demod_stream_oneshot(raw)
+        assert O.pack_bits_le(bits).tobytes().hex() == rec["bits"], name
+        assert [int(np.signbit(v)) for v in d[:4]] == rec["first_disc_signbit"], name
+    # -0.0 appears exactly when re(y0) < 0 and im(y0) > 0
+    assert g["np"]["first_disc_signbit"][1] == 1 and g["pp"]["first_disc_signbit"][1] == 0
+
+
+def test_quantize_reference_tests():
+    """The reference's own tests/test_dsp.py:4-33, as data."""
+    g = load_json("quantize.json")
+    vals = np.array([float(v) for v in g["in"]])
+    assert O.quantize(vals).tolist() == g["out"] == [1, 0, 1, 0, 0, 1]
+    rq = np.random.default_rng(42).uniform(-10, 10, 1000)
+    out = O.quantize(rq)
+    assert O.pack_bits_le(out).tobytes().hex() == g["rng42_out_packed"]
+    assert np.array_equal(out, (rq < 0).astype(np.uint8))
+
+
+def test_crc_and_bitswap_kats():
+    """tests/test_protocol.py:3-36 known answers."""
+    assert O.swap_bit_order(0x01) == 0x80 and O.swap_bit_order(0xF0) == 0x0F
+    assert O.swap_bit_order(0xAA) == 0x55 and O.swap_bit_order(0xFF) == 0xFF
+    ota = bytes.fromhex("07C02B0B80408EFF")
+    data = bytes(O.swap_bit_order(b) for b in ota)
+    assert data.hex() == "e003d4d0010271ff" and O.crc16_ccitt(data) == 0
+    bad = bytearray(data); bad[3] ^= 0x10
+    assert O.crc16_ccitt(bytes(bad)) != 0
+    for hx in synth.OTA_PACKETS:
+        d = bytes(O.swap_bit_order(b) for b in bytes.fromhex(hx))
+        assert O.crc16_ccitt(d[2:]) == 0
