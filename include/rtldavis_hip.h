@@ -1,0 +1,152 @@
+/*
+ * rtldavis_hip.h - C ABI of librtldavis_hip.so: the MI355X (gfx950) implementation of
+ * rtldavis's IQ -> bits -> packets path.
+ *
+ * The reference has no FFI for this path (it is pure Python/NumPy, and the legacy Go
+ * twin is pure Go), so each entry point below names the reference function whose work
+ * it takes over.  "py" = /root/reference/src/rtldavis/dsp.py, "go" = /root/reference/dsp/dsp.go.
+ * The ctypes stub a maintainer of the reference would add is in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns RD_OK (0) or a
+ * negative rd_status; outputs are caller-allocated; no callbacks; no global state other
+ * than the per-process HIP context, which is created lazily by the first call that
+ * needs the device (never by rd_create / rd_batch_create with defer_device != 0), so
+ * a handle may be created before fork() (py worker model: __main__.py:277, worker.py:29).
+ * rd_last_error() returns a thread-local, human-readable message for the last failure.
+ */
+#ifndef RTLDAVIS_HIP_H
+#define RTLDAVIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_MAX_PREAMBLE 64   /* symbols */
+#define RD_MAX_PKT_BYTES 32  /* (packet_symbols + 7) / 8 */
+
+typedef enum rd_status {
+    RD_OK = 0,
+    RD_ERR_ARG = -1,      /* bad argument / "Incompatible array sizes" (py:32-36,145-149) */
+    RD_ERR_DEVICE = -2,   /* HIP failure: no device, launch or copy error */
+    RD_ERR_CAPACITY = -3, /* caller's output array too small; *n holds the needed count */
+    RD_ERR_STATE = -4     /* call order violated (e.g. results before run) */
+} rd_status;
+
+/* py:101-125 PacketConfig / go:172-218 NewPacketConfig.  Derived constants are computed inside. */
+typedef struct rd_config {
+    int32_t bit_rate;
+    int32_t symbol_length;    /* samples per symbol */
+    int32_t preamble_symbols; /* <= RD_MAX_PREAMBLE */
+    int32_t packet_symbols;   /* <= 8 * RD_MAX_PKT_BYTES */
+    int32_t block_size;       /* samples per demodulate() call; multiple of 4 */
+    uint8_t preamble[RD_MAX_PREAMBLE]; /* 0/1 per symbol */
+} rd_config;
+
+/* py:12-17 Packet, plus where it came from.  index is the window-relative q_idx of py:190-246. */
+typedef struct rd_packet {
+    int32_t stream; /* stream number in a batch (0 for rd_handle) */
+    int32_t call;   /* block number b of the demodulate() call that returns it */
+    int32_t index;
+    int32_t nbytes;
+    uint8_t data[RD_MAX_PKT_BYTES];
+    double rssi;
+    double snr;
+} rd_packet;
+
+/* Per-launch timing of the kernels of one rd_batch_run (HIP events on the run's stream). */
+typedef struct rd_timing {
+    float demod_ms;  /* fused LUT+rotate+FIR+discriminator-sign+pack kernel */
+    float fixup_ms;  /* exact re-evaluation of guard-band samples */
+    float search_ms; /* preamble search */
+    float slice_ms;  /* slice + RSSI/SNR */
+    float total_ms;
+} rd_timing;
+
+const char *rd_last_error(void);
+/* Number of visible HIP devices (<0 on error).  Does not create a context. */
+int rd_device_count(void);
+/* Bind this process/thread's later calls to a device (hipSetDevice). */
+int rd_set_device(int device);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming demodulator: one stream, one block per call, state carried across calls.
+ * Replaces py:128-253 Demodulator / go:220-310.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rd_demod rd_demod;
+
+/* py:129-137 __init__ (no device work; safe before fork). */
+int rd_create(const rd_config *cfg, rd_demod **out);
+void rd_destroy(rd_demod *h);
+/* py:248-253 reset. */
+int rd_reset(rd_demod *h);
+/*
+ * py:139-169 demodulate.  `samples` is either uint8 interleaved I,Q (is_complex = 0,
+ * count = 2 * block_size bytes; py:151-152) or complex128 (is_complex = 1, count =
+ * block_size elements, interleaved re,im doubles; py:144-150).  Any other count returns
+ * RD_ERR_ARG ("Incompatible array sizes").  Packets are written in the reference's order
+ * (phase-major search order, per-call dedupe, py:171-205).
+ */
+int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_complex, rd_packet *out, int cap, int *n);
+/* Lazily materialised mirrors of the reference's state arrays after the last call:
+ * discriminated f64[2*block_size] (py:134), filtered complex128[block_size+1] as
+ * interleaved doubles (py:133), quantized uint8[buffer_length] 0/1 (py:135). */
+int rd_copy_discriminated(rd_demod *h, double *out, size_t n);
+int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_complex);
+int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batch demodulator: n_streams independent streams of n_blocks blocks each, all demodulated
+ * from reset in one pass.  Output is, per stream and per call, exactly what n_blocks
+ * successive Demodulator.demodulate() calls return (py:139-169).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rd_batch rd_batch;
+
+int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks, rd_batch **out);
+void rd_batch_destroy(rd_batch *b);
+/* Device address of the resident input buffer, uint8 [n_streams][n_blocks*block_size][2]
+ * (dense, stream-major), so a producer on the GPU can fill it in place. */
+int rd_batch_input_ptr(rd_batch *b, void **dev_ptr, size_t *nbytes);
+/* Host -> device copy of the whole input (PCIe; not part of the timed region of bench.py). */
+int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbytes);
+/* Run the whole path on the resident input.  hip_stream: a hipStream_t (NULL = default
+ * stream).  Asynchronous; rd_batch_results synchronises. */
+int rd_batch_run(rd_batch *b, void *hip_stream);
+/* Packets of the last run, sorted by (stream, call, reference order).  *n = count. */
+int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n);
+/* Packed bitstream of one stream: sample t -> byte t/8, bit t%8 (LSB first);
+ * nbytes >= (n_blocks*block_size + 7) / 8.  (go:105-113 Pack is the nearest reference stage;
+ * the Python reference keeps one byte per bit, py:135.) */
+int rd_batch_copy_bits(rd_batch *b, int stream, uint8_t *out, size_t nbytes);
+/* Full-precision discriminator output d[t0 .. t0+n) of one stream (py:76-90), float64. */
+int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out, size_t n);
+/* Enable per-kernel HIP-event timing (adds events to the stream) and read the last run's. */
+int rd_batch_set_timing(rd_batch *b, int enabled);
+int rd_batch_get_timing(rd_batch *b, rd_timing *out);
+/* Counters of the last run: guard-band runs re-evaluated exactly, raw preamble matches. */
+int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t *matches);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage functions on host arrays (caller-allocated out-params, like the reference's).
+ * Each runs its own float64 kernel on the device.
+ * ------------------------------------------------------------------------------------------- */
+/* py:20-39 ByteToCmplxLUT.execute / go:26-44: n_bytes must equal 2 * n_cplx else RD_ERR_ARG. */
+int rd_lut_execute(const uint8_t *in_bytes, size_t n_bytes, double *out_cplx, size_t n_cplx);
+/* py:42-49 rotate_fs4 / go:46-63 RotateFs4 (in == out allowed). */
+int rd_rotate_fs4(const double *in_cplx, double *out_cplx, size_t n_cplx);
+/* py:52-73 fir9 / go:65-83 FIR9: out[i] = sum_m c[m] * in[i+m], n_out <= n_in - 8. */
+int rd_fir9(const double *in_cplx, size_t n_in, double *out_cplx, size_t n_out);
+/* py:76-90 discriminate / go:85-95 Discriminate: n_out = n_in - 1. */
+int rd_discriminate(const double *in_cplx, size_t n_in, double *out, size_t n_out);
+/* py:93-98 quantize / go:97-103 Quantize: sign bit. */
+int rd_quantize(const double *in, uint8_t *out, size_t n);
+/* go:105-113 Pack + go:115-131 Search / py:171-188 _search on a 0/1-per-byte buffer:
+ * indices in the reference's order; *n = count (RD_ERR_CAPACITY if > cap). */
+int rd_search(const rd_config *cfg, const uint8_t *quantized, size_t n, int32_t *indices, int cap, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTLDAVIS_HIP_H */

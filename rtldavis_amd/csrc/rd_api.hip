@@ -1,0 +1,753 @@
+// rd_api.hip - C ABI of librtldavis_hip.so (see include/rtldavis_hip.h).
+//
+// Host-side orchestration only: buffer management, kernel sequencing, and the per-call
+// ordering/dedupe of Demodulator._slice (py:190-205).  All arithmetic of the path runs in
+// the kernels of rd_kernels.hip; there is no CPU fallback - without a usable HIP device
+// every compute entry point returns RD_ERR_DEVICE.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rd_internal.h"
+#include "rd_math.h"
+
+// ------------------------------------------------------------------------------------------
+// errors / device context
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(RD_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *rd_last_error(void) { return g_err.c_str(); }
+
+static pid_t g_hip_pid = 0;  // pid that first touched the device through this library
+
+// HIP state does not survive fork(): a child of a process that already used the device
+// must not reuse it.  Handles created before fork hold no device state (lazy init).
+static int ensure_device() {
+    const pid_t me = getpid();
+    if (g_hip_pid != 0 && g_hip_pid != me)
+        return fail(RD_ERR_DEVICE, "HIP was initialised in parent process %d before fork(); "
+                                   "create the device state in the child instead", (int)g_hip_pid);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RD_ERR_DEVICE, "no HIP device available (%s); librtldavis_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    g_hip_pid = me;
+    return RD_OK;
+}
+
+extern "C" int rd_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RD_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" int rd_set_device(int device) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// configuration (py:101-125)
+// ------------------------------------------------------------------------------------------
+static int make_devcfg(const rd_config *c, rd_devcfg *d) {
+    if (!c) return fail(RD_ERR_ARG, "null config");
+    if (c->symbol_length < 1 || c->preamble_symbols < 1 || c->preamble_symbols > RD_MAX_PREAMBLE ||
+        c->packet_symbols < 1 || c->packet_symbols > 8 * RD_MAX_PKT_BYTES)
+        return fail(RD_ERR_ARG, "unsupported packet configuration");
+    if (c->packet_symbols < c->preamble_symbols)
+        return fail(RD_ERR_ARG, "packet_symbols < preamble_symbols is not supported");
+    if (c->block_size < 32 || c->block_size % 4)
+        return fail(RD_ERR_ARG, "block_size must be a multiple of 4 and >= 32 (rotate_fs4, py:46-49)");
+    d->S = c->symbol_length;
+    d->P = c->preamble_symbols;
+    d->K = c->packet_symbols;
+    d->B = c->block_size;
+    d->PL = c->preamble_symbols * c->symbol_length;
+    const long packet_length = (long)c->packet_symbols * c->symbol_length;
+    const long L = (packet_length / c->block_size + 2) * (long)c->block_size;
+    if (L > 0x3FFFFFFF) return fail(RD_ERR_ARG, "buffer_length too large");
+    d->L = (int32_t)L;
+    d->nbytes = (c->packet_symbols + 7) / 8;
+    d->pre_mask = 0;
+    for (int i = 0; i < c->preamble_symbols; i++) {
+        if (c->preamble[i] > 1) return fail(RD_ERR_ARG, "preamble symbols must be 0 or 1");
+        d->pre_mask |= (uint64_t)c->preamble[i] << i;
+    }
+    return RD_OK;
+}
+
+// Reference order inside one call: search is phase-major then ascending (py:175-186),
+// slice keeps the first occurrence of each byte string (py:203-205).
+static void order_and_dedupe(std::vector<rd_packet> &recs, int S) {
+    std::sort(recs.begin(), recs.end(), [S](const rd_packet &a, const rd_packet &b) {
+        if (a.stream != b.stream) return a.stream < b.stream;
+        if (a.call != b.call) return a.call < b.call;
+        const int pa = a.index % S, pb = b.index % S;
+        if (pa != pb) return pa < pb;
+        return a.index < b.index;
+    });
+    std::vector<rd_packet> out;
+    out.reserve(recs.size());
+    size_t group = 0;
+    for (size_t i = 0; i < recs.size(); i++) {
+        if (i == 0 || recs[i].stream != recs[i - 1].stream || recs[i].call != recs[i - 1].call) group = out.size();
+        bool dup = false;
+        for (size_t k = group; k < out.size() && !dup; k++)
+            dup = memcmp(out[k].data, recs[i].data, (size_t)recs[i].nbytes) == 0;
+        if (!dup) out.push_back(recs[i]);
+    }
+    recs.swap(out);
+}
+
+// ------------------------------------------------------------------------------------------
+// batch demodulator
+// ------------------------------------------------------------------------------------------
+struct rd_batch {
+    rd_config cfg;
+    rd_devcfg dc;
+    int n_streams, n_blocks;
+    long n_samples;      // per stream
+    size_t bits_stride;  // words per stream
+    bool dev_ready = false, fast_ok = false, ran = false, timing = false;
+    uint8_t *d_iq = nullptr;
+    size_t iq_bytes = 0;
+    uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
+    rd_match *d_matches = nullptr;
+    rd_packet *d_recs = nullptr;
+    uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {};
+    uint32_t h_cnt[RD_CNT_SLOTS] = {};
+    uint64_t last_fix = 0, last_match = 0;
+    rd_timing last_timing = {};
+};
+
+static rd_layout batch_layout(const rd_batch *b) {
+    rd_layout l;
+    l.iq = b->d_iq;
+    l.stream_stride = (size_t)b->n_samples * 2;
+    l.n_streams = b->n_streams;
+    l.n_samples = (uint32_t)b->n_samples;
+    l.hist_mode = 0;
+    l.valid_from = 0;
+    l.bits = b->d_bits;
+    l.bits_stride = b->bits_stride;
+    return l;
+}
+
+extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks, rd_batch **out) {
+    if (!out) return fail(RD_ERR_ARG, "null out");
+    rd_devcfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    if (n_streams < 1 || n_blocks < 1) return fail(RD_ERR_ARG, "n_streams and n_blocks must be >= 1");
+    const long n = (long)n_blocks * cfg->block_size;
+    const uint64_t runs = (uint64_t)n_streams * ((n + RD_RUN - 1) / RD_RUN);
+    if (n > 0x7FFFFFF0L || runs > 0xFFFFFFFFull) return fail(RD_ERR_ARG, "batch too large for 32-bit run ids");
+    rd_batch *b = new rd_batch();
+    b->cfg = *cfg;
+    b->dc = dc;
+    b->n_streams = n_streams;
+    b->n_blocks = n_blocks;
+    b->n_samples = n;
+    b->bits_stride = (size_t)((n + 31) / 32);
+    b->fast_ok = ((size_t)n * 2) % 16 == 0;  // 16-byte aligned streams for the LDS-DMA loads
+    *out = b;
+    return RD_OK;
+}
+
+static int batch_alloc(rd_batch *b) {
+    if (b->dev_ready) return RD_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    const uint64_t runs = (uint64_t)b->n_streams * b->bits_stride;
+    b->iq_bytes = (size_t)b->n_streams * b->n_samples * 2;
+    b->fix_cap = (uint32_t)std::min<uint64_t>(runs, std::max<uint64_t>(4096, runs / 8));
+    b->match_cap = (uint32_t)std::min<uint64_t>((uint64_t)b->n_streams * (16 + 4ull * b->n_blocks), 1u << 26);
+    b->rec_cap = 2 * b->match_cap;
+    HIPCHK(hipMalloc(&b->d_iq, b->iq_bytes + RD_INPUT_PAD));
+    HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));
+    HIPCHK(hipMalloc(&b->d_bits, runs * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b->d_fix, (size_t)b->fix_cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
+    HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+    for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
+    b->dev_ready = true;
+    return RD_OK;
+}
+
+extern "C" void rd_batch_destroy(rd_batch *b) {
+    if (!b) return;
+    if (b->dev_ready && g_hip_pid == getpid()) {
+        hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
+        hipFree(b->d_matches); hipFree(b->d_recs);
+        for (auto &e : b->ev) if (e) hipEventDestroy(e);
+    }
+    delete b;
+}
+
+extern "C" int rd_batch_input_ptr(rd_batch *b, void **dev_ptr, size_t *nbytes) {
+    if (!b || !dev_ptr) return fail(RD_ERR_ARG, "null argument");
+    int rc = batch_alloc(b);
+    if (rc) return rc;
+    *dev_ptr = b->d_iq;
+    if (nbytes) *nbytes = b->iq_bytes;
+    return RD_OK;
+}
+
+extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbytes) {
+    if (!b || !iq_host) return fail(RD_ERR_ARG, "null argument");
+    int rc = batch_alloc(b);
+    if (rc) return rc;
+    if (nbytes != b->iq_bytes) {
+        return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu bytes, expected %zu", nbytes, b->iq_bytes);
+    }
+    HIPCHK(hipMemcpy(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice));
+    return RD_OK;
+}
+
+// search + slice part of a run (re-issued on list overflow)
+static void batch_search_slice(rd_batch *b, hipStream_t st) {
+    const rd_layout lay = batch_layout(b);
+    const long B = b->dc.B, L = b->dc.L;
+    rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
+                     b->dc, b->d_matches, b->match_cap, b->d_cnt, st);
+    if (b->timing) hipEventRecord(b->ev[3], st);
+    rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
+                    b->d_recs, b->rec_cap, b->d_cnt, st);
+    if (b->timing) hipEventRecord(b->ev[4], st);
+}
+
+extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
+    if (!b) return fail(RD_ERR_ARG, "null batch");
+    int rc = batch_alloc(b);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    b->stream = st;
+    const rd_layout lay = batch_layout(b);
+    HIPCHK(hipMemsetAsync(b->d_cnt, 0, RD_CNT_SLOTS * sizeof(uint32_t), st));
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
+    if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, b->d_cnt, st);
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
+    rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, b->fast_ok ? 0 : 1, st);
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[2], st));
+    batch_search_slice(b, st);
+    HIPCHK(hipGetLastError());
+    b->ran = true;
+    return RD_OK;
+}
+
+// Synchronise, handle list overflows (re-running what is needed), fetch the counters.
+static int batch_finish(rd_batch *b) {
+    if (!b->ran) return fail(RD_ERR_STATE, "rd_batch_run has not been called");
+    hipStream_t st = b->stream;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(b->h_cnt, b->d_cnt, sizeof b->h_cnt, hipMemcpyDeviceToHost));
+        bool redo_search = false;
+        if (b->fast_ok && b->h_cnt[RD_CNT_FIX] > b->fix_cap) {
+            // guard list overflowed (degenerate input): re-evaluate every run exactly
+            const rd_layout lay = batch_layout(b);
+            rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, 1, st);
+            uint32_t cap = b->fix_cap;  // mark handled
+            HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
+            b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
+            redo_search = true;
+        } else if (attempt == 0) {
+            b->last_fix = b->h_cnt[RD_CNT_FIX];
+        }
+        if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
+            hipFree(b->d_matches); hipFree(b->d_recs);
+            b->match_cap = b->h_cnt[RD_CNT_MATCH] + 1024;
+            b->rec_cap = 2 * b->match_cap;
+            HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
+            HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+            redo_search = true;
+        }
+        if (!redo_search) {
+            b->last_match = b->h_cnt[RD_CNT_MATCH];
+            if (b->timing) {
+                rd_timing &t = b->last_timing;
+                hipEventElapsedTime(&t.demod_ms, b->ev[0], b->ev[1]);
+                hipEventElapsedTime(&t.fixup_ms, b->ev[1], b->ev[2]);
+                hipEventElapsedTime(&t.search_ms, b->ev[2], b->ev[3]);
+                hipEventElapsedTime(&t.slice_ms, b->ev[3], b->ev[4]);
+                hipEventElapsedTime(&t.total_ms, b->ev[0], b->ev[4]);
+            }
+            return RD_OK;
+        }
+        const uint32_t zero[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
+        batch_search_slice(b, st);
+    }
+    return fail(RD_ERR_DEVICE, "result lists kept overflowing");
+}
+
+extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
+    if (!b || !n) return fail(RD_ERR_ARG, "null argument");
+    int rc = batch_finish(b);
+    if (rc) return rc;
+    const uint32_t nrec = std::min(b->h_cnt[RD_CNT_REC], b->rec_cap);
+    std::vector<rd_packet> recs(nrec);
+    if (nrec) HIPCHK(hipMemcpy(recs.data(), b->d_recs, (size_t)nrec * sizeof(rd_packet), hipMemcpyDeviceToHost));
+    order_and_dedupe(recs, b->dc.S);
+    *n = (int)recs.size();
+    if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
+    if (!recs.empty()) {
+        if (!out) return fail(RD_ERR_ARG, "null out");
+        memcpy(out, recs.data(), recs.size() * sizeof(rd_packet));
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_batch_copy_bits(rd_batch *b, int stream, uint8_t *out, size_t nbytes) {
+    if (!b || !out) return fail(RD_ERR_ARG, "null argument");
+    if (stream < 0 || stream >= b->n_streams) return fail(RD_ERR_ARG, "stream out of range");
+    const size_t need = (size_t)((b->n_samples + 7) / 8);
+    if (nbytes < need) return fail(RD_ERR_ARG, "bit buffer too small: %zu < %zu", nbytes, need);
+    int rc = batch_finish(b);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, (const uint8_t *)(b->d_bits + (size_t)stream * b->bits_stride), need, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out, size_t n) {
+    if (!b || !out) return fail(RD_ERR_ARG, "null argument");
+    if (stream < 0 || stream >= b->n_streams || t0 + n > (size_t)b->n_samples)
+        return fail(RD_ERR_ARG, "range out of bounds");
+    int rc = batch_alloc(b);
+    if (rc) return rc;
+    if (n == 0) return RD_OK;
+    double *d = nullptr;
+    HIPCHK(hipMalloc(&d, n * sizeof(double)));
+    rd_launch_disc(batch_layout(b), stream, (long)t0, (long)n, d, b->stream);
+    hipError_t e = hipMemcpyAsync(out, d, n * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(RD_ERR_DEVICE, "copy_discriminated: %s", hipGetErrorString(e));
+    return RD_OK;
+}
+
+extern "C" int rd_batch_set_timing(rd_batch *b, int enabled) {
+    if (!b) return fail(RD_ERR_ARG, "null batch");
+    b->timing = enabled != 0;
+    return RD_OK;
+}
+
+extern "C" int rd_batch_get_timing(rd_batch *b, rd_timing *out) {
+    if (!b || !out) return fail(RD_ERR_ARG, "null argument");
+    if (!b->timing) return fail(RD_ERR_STATE, "timing not enabled");
+    int rc = batch_finish(b);
+    if (rc) return rc;
+    *out = b->last_timing;
+    return RD_OK;
+}
+
+extern "C" int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t *matches) {
+    if (!b) return fail(RD_ERR_ARG, "null batch");
+    int rc = batch_finish(b);
+    if (rc) return rc;
+    if (fixup_runs) *fixup_runs = b->last_fix;
+    if (matches) *matches = b->last_match;
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming demodulator (py:128-253)
+// ------------------------------------------------------------------------------------------
+struct rd_demod {
+    rd_config cfg;
+    rd_devcfg dc;
+    bool dev_ready = false;
+    bool cplx_mode = false;  // switched on by the first complex128 block, until reset
+    long seen = 0;           // blocks demodulated since reset
+    // byte ring: [hdr 32 B][prev 2B][cur 2B][pad]; complex ring: [hdr 16][prev B][cur B] complex128
+    uint8_t *d_ring = nullptr;
+    double *d_cring = nullptr;
+    uint8_t *d_stage = nullptr;  // staging for byte input while in complex mode
+    uint32_t *d_blockbits = nullptr, *d_win[2] = {nullptr, nullptr}, *d_fix = nullptr, *d_cnt = nullptr;
+    int cur_win = 0;
+    rd_match *d_matches = nullptr;
+    rd_packet *d_recs = nullptr;
+    double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
+    uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
+    bool fast_ok = false;
+};
+
+extern "C" int rd_create(const rd_config *cfg, rd_demod **out) {
+    if (!out) return fail(RD_ERR_ARG, "null out");
+    rd_devcfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    rd_demod *h = new rd_demod();
+    h->cfg = *cfg;
+    h->dc = dc;
+    h->fast_ok = (dc.B % 8) == 0;
+    *out = h;
+    return RD_OK;
+}
+
+static size_t ring_cur_off(const rd_demod *h) { return 32 + 2 * (size_t)h->dc.B; }
+
+static int demod_alloc(rd_demod *h) {
+    if (h->dev_ready) return RD_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L;
+    const size_t ring_bytes = 32 + 4 * B + RD_INPUT_PAD;
+    HIPCHK(hipMalloc(&h->d_ring, ring_bytes));
+    HIPCHK(hipMemset(h->d_ring, 127, ring_bytes));
+    HIPCHK(hipMalloc(&h->d_stage, 2 * B));
+    h->fix_cap = (uint32_t)((B + 31) / 32);
+    h->match_cap = (uint32_t)(B + 1);
+    h->rec_cap = (uint32_t)(B + 1);
+    HIPCHK(hipMalloc(&h->d_blockbits, ((B + 31) / 32) * 4));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc(&h->d_win[i], ((L + 31) / 32) * 4));
+        HIPCHK(hipMemset(h->d_win[i], 0, ((L + 31) / 32) * 4));
+    }
+    HIPCHK(hipMalloc(&h->d_fix, (size_t)h->fix_cap * 4));
+    HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
+    HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
+    HIPCHK(hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(rd_packet)));
+    HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
+    h->dev_ready = true;
+    return RD_OK;
+}
+
+extern "C" void rd_destroy(rd_demod *h) {
+    if (!h) return;
+    if (h->dev_ready && g_hip_pid == getpid()) {
+        hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_stage); hipFree(h->d_blockbits);
+        hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
+        hipFree(h->d_matches); hipFree(h->d_recs); hipFree(h->d_tmp);
+    }
+    delete h;
+}
+
+extern "C" int rd_reset(rd_demod *h) {
+    if (!h) return fail(RD_ERR_ARG, "null handle");
+    h->seen = 0;
+    h->cplx_mode = false;
+    if (h->dev_ready) {
+        const size_t L = (size_t)h->dc.L;
+        for (int i = 0; i < 2; i++) HIPCHK(hipMemset(h->d_win[i], 0, ((L + 31) / 32) * 4));
+    }
+    return RD_OK;
+}
+
+// first readable sample relative to the newest block's sample 0
+static long demod_valid_from(const rd_demod *h, long seen_before) {
+    const long B = h->dc.B;
+    if (seen_before <= 0) return 0;
+    if (seen_before == 1) return -B;
+    return -(B + 16);
+}
+
+static rd_layout demod_layout(const rd_demod *h, long seen_before) {
+    rd_layout l;
+    l.iq = h->d_ring + ring_cur_off(h);
+    l.stream_stride = 0;
+    l.n_streams = 1;
+    l.n_samples = (uint32_t)h->dc.B;
+    l.hist_mode = seen_before > 0 ? 1 : 0;
+    l.valid_from = demod_valid_from(h, seen_before);
+    l.bits = h->d_blockbits;
+    l.bits_stride = (size_t)((h->dc.B + 31) / 32);
+    return l;
+}
+
+static rd_cplx_layout demod_clayout(const rd_demod *h, long seen_before) {
+    rd_cplx_layout l;
+    l.x = h->d_cring + 2 * (16 + (size_t)h->dc.B);
+    l.valid_from = demod_valid_from(h, seen_before);
+    l.n = h->dc.B;
+    return l;
+}
+
+// Switch to the complex ring: LUT-convert the byte ring (py:26,38-39 - what the reference
+// keeps in raw_samples) so history carries over exactly.
+static int demod_enter_cplx(rd_demod *h) {
+    const size_t B = (size_t)h->dc.B;
+    if (!h->d_cring) HIPCHK(hipMalloc(&h->d_cring, 2 * (16 + 2 * B) * sizeof(double)));
+    rd_launch_lut(h->d_ring, h->d_cring, 16 + 2 * B, nullptr);
+    HIPCHK(hipGetLastError());
+    h->cplx_mode = true;
+    return RD_OK;
+}
+
+extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_complex, rd_packet *out, int cap,
+                              int *n) {
+    if (!h || !samples || !n) return fail(RD_ERR_ARG, "null argument");
+    const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L;
+    // py:32-36 / py:145-149
+    if ((is_complex && count != B) || (!is_complex && count != 2 * B))
+        return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu, expected %zu", count, is_complex ? B : 2 * B);
+    int rc = demod_alloc(h);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    if (is_complex && !h->cplx_mode) {
+        rc = demod_enter_cplx(h);
+        if (rc) return rc;
+    }
+    const long seen_before = h->seen;
+    // roll the raw ring left by one block (py:140,154): hdr <- tail of prev, prev <- cur
+    if (!h->cplx_mode) {
+        uint8_t *r = h->d_ring;
+        if (seen_before > 0) {
+            HIPCHK(hipMemcpyAsync(r, r + 32 + 2 * B - 32, 32, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(r + 32, r + 32 + 2 * B, 2 * B, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, samples, 2 * B, hipMemcpyHostToDevice, st));
+    } else {
+        double *r = h->d_cring;
+        if (seen_before > 0) {
+            HIPCHK(hipMemcpyAsync(r, r + 2 * B, 32 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(r + 32, r + 32 + 2 * B, 2 * B * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        if (is_complex) {
+            HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, samples, 2 * B * sizeof(double), hipMemcpyHostToDevice, st));
+        } else {
+            HIPCHK(hipMemcpyAsync(h->d_stage, samples, 2 * B, hipMemcpyHostToDevice, st));
+            rd_launch_lut(h->d_stage, r + 32 + 2 * B, B, st);
+        }
+    }
+    HIPCHK(hipMemsetAsync(h->d_cnt, 0, RD_CNT_SLOTS * 4, st));
+    if (!h->cplx_mode) {
+        const rd_layout lay = demod_layout(h, seen_before);
+        if (h->fast_ok) rd_launch_demod(lay, h->d_fix, h->fix_cap, h->d_cnt, st);
+        rd_launch_fixup(lay, h->d_fix, h->fix_cap, h->d_cnt, h->fast_ok ? 0 : 1, st);
+    } else {
+        rd_launch_cplx_bits(demod_clayout(h, seen_before), h->d_blockbits, st);
+    }
+    // quantized <- roll(quantized, -B) with the new bits at the end (py:157,163-166)
+    const int nw = h->cur_win ^ 1;
+    rd_launch_window_update(h->d_win[nw], h->d_win[h->cur_win], (long)L, h->d_blockbits, (long)B, st);
+    h->cur_win = nw;
+    // whole-buffer search, keep q <= B (py:171-188,194)
+    rd_launch_search(h->d_win[nw], 0, 1, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
+    if (!h->cplx_mode)
+        rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], 0, (long)L, h->dc, h->d_matches, h->match_cap, 0, 0,
+                        (int)seen_before, h->d_recs, h->rec_cap, h->d_cnt, st);
+    else
+        rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
+                             (int)seen_before, h->d_recs, h->rec_cap, h->d_cnt, st);
+    HIPCHK(hipGetLastError());
+    uint32_t cnt[RD_CNT_SLOTS];
+    HIPCHK(hipMemcpyAsync(cnt, h->d_cnt, sizeof cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->seen = seen_before + 1;
+    const uint32_t nrec = std::min(cnt[RD_CNT_REC], h->rec_cap);
+    std::vector<rd_packet> recs(nrec);
+    if (nrec) HIPCHK(hipMemcpy(recs.data(), h->d_recs, (size_t)nrec * sizeof(rd_packet), hipMemcpyDeviceToHost));
+    order_and_dedupe(recs, h->dc.S);
+    *n = (int)recs.size();
+    if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
+    if (!recs.empty()) {
+        if (!out) return fail(RD_ERR_ARG, "null out");
+        memcpy(out, recs.data(), recs.size() * sizeof(rd_packet));
+    }
+    return RD_OK;
+}
+
+extern "C" int rd_copy_discriminated(rd_demod *h, double *out, size_t n) {
+    if (!h || !out) return fail(RD_ERR_ARG, "null argument");
+    const size_t B = (size_t)h->dc.B;
+    if (n != 2 * B) return fail(RD_ERR_ARG, "discriminated has %zu elements", 2 * B);
+    if (h->seen == 0) {  // py:134 zeros
+        memset(out, 0, n * sizeof(double));
+        return RD_OK;
+    }
+    // discriminated = d over [-B, B) relative to the newest block (py:156,162)
+    if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), 0, -(long)B, 2 * (long)B, h->d_tmp, nullptr);
+    else rd_launch_cplx_disc(demod_clayout(h, h->seen - 1), -(long)B, 2 * (long)B, h->d_tmp, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_complex) {
+    if (!h || !out_interleaved) return fail(RD_ERR_ARG, "null argument");
+    const size_t B = (size_t)h->dc.B;
+    if (n_complex != B + 1) return fail(RD_ERR_ARG, "filtered has %zu elements", B + 1);
+    if (h->seen == 0) {
+        memset(out_interleaved, 0, 2 * n_complex * sizeof(double));
+        return RD_OK;
+    }
+    // filtered[j] = f[j-1] relative to the newest block (py:155,161)
+    if (!h->cplx_mode) rd_launch_filtered(demod_layout(h, h->seen - 1), 0, -1, (long)B + 1, h->d_tmp, nullptr);
+    else rd_launch_cplx_filtered(demod_clayout(h, h->seen - 1), -1, (long)B + 1, h->d_tmp, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out_interleaved, h->d_tmp, 2 * n_complex * sizeof(double), hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n) {
+    if (!h || !out) return fail(RD_ERR_ARG, "null argument");
+    const size_t L = (size_t)h->dc.L;
+    if (n != L) return fail(RD_ERR_ARG, "quantized has %zu elements", L);
+    if (!h->dev_ready) {  // py:135 zeros
+        memset(out, 0, n);
+        return RD_OK;
+    }
+    std::vector<uint32_t> words((L + 31) / 32);
+    HIPCHK(hipMemcpy(words.data(), h->d_win[h->cur_win], words.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t t = 0; t < L; t++) out[t] = (uint8_t)((words[t >> 5] >> (t & 31)) & 1u);  // unpack only
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage functions on host arrays
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+
+#define STAGE_PROLOGUE()            \
+    do {                            \
+        int rc_ = ensure_device();  \
+        if (rc_) return rc_;        \
+    } while (0)
+
+extern "C" int rd_lut_execute(const uint8_t *in_bytes, size_t n_bytes, double *out_cplx, size_t n_cplx) {
+    if (n_bytes != 2 * n_cplx) return fail(RD_ERR_ARG, "Incompatible array sizes: in_bytes.size=%zu, out_cplx.size=%zu", n_bytes, n_cplx);
+    if (n_cplx == 0) return RD_OK;
+    if (!in_bytes || !out_cplx) return fail(RD_ERR_ARG, "null argument");
+    STAGE_PROLOGUE();
+    DevBuf a, b;
+    HIPCHK(hipMalloc(&a.p, n_bytes));
+    HIPCHK(hipMalloc(&b.p, n_cplx * 16));
+    HIPCHK(hipMemcpy(a.p, in_bytes, n_bytes, hipMemcpyHostToDevice));
+    rd_launch_lut((const uint8_t *)a.p, (double *)b.p, n_cplx, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out_cplx, b.p, n_cplx * 16, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_rotate_fs4(const double *in_cplx, double *out_cplx, size_t n_cplx) {
+    if (n_cplx == 0) return RD_OK;
+    if (!in_cplx || !out_cplx) return fail(RD_ERR_ARG, "null argument");
+    STAGE_PROLOGUE();
+    DevBuf a, b;
+    HIPCHK(hipMalloc(&a.p, n_cplx * 16));
+    HIPCHK(hipMalloc(&b.p, n_cplx * 16));
+    HIPCHK(hipMemcpy(a.p, in_cplx, n_cplx * 16, hipMemcpyHostToDevice));
+    rd_launch_rotate((const double *)a.p, (double *)b.p, n_cplx, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out_cplx, b.p, n_cplx * 16, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_fir9(const double *in_cplx, size_t n_in, double *out_cplx, size_t n_out) {
+    if (n_in < 9 || n_out > n_in - 8) return fail(RD_ERR_ARG, "fir9: n_out must be <= n_in - 8");
+    if (n_out == 0) return RD_OK;
+    if (!in_cplx || !out_cplx) return fail(RD_ERR_ARG, "null argument");
+    STAGE_PROLOGUE();
+    DevBuf a, b;
+    HIPCHK(hipMalloc(&a.p, n_in * 16));
+    HIPCHK(hipMalloc(&b.p, n_out * 16));
+    HIPCHK(hipMemcpy(a.p, in_cplx, n_in * 16, hipMemcpyHostToDevice));
+    rd_launch_fir9((const double *)a.p, (double *)b.p, n_out, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out_cplx, b.p, n_out * 16, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_discriminate(const double *in_cplx, size_t n_in, double *out, size_t n_out) {
+    if (n_in < 1 || n_out != n_in - 1) return fail(RD_ERR_ARG, "discriminate: n_out must be n_in - 1");
+    if (n_out == 0) return RD_OK;
+    if (!in_cplx || !out) return fail(RD_ERR_ARG, "null argument");
+    STAGE_PROLOGUE();
+    DevBuf a, b;
+    HIPCHK(hipMalloc(&a.p, n_in * 16));
+    HIPCHK(hipMalloc(&b.p, n_out * 8));
+    HIPCHK(hipMemcpy(a.p, in_cplx, n_in * 16, hipMemcpyHostToDevice));
+    rd_launch_discriminate((const double *)a.p, (double *)b.p, n_out, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, b.p, n_out * 8, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_quantize(const double *in, uint8_t *out, size_t n) {
+    if (n == 0) return RD_OK;
+    if (!in || !out) return fail(RD_ERR_ARG, "null argument");
+    STAGE_PROLOGUE();
+    DevBuf a, b;
+    HIPCHK(hipMalloc(&a.p, n * 8));
+    HIPCHK(hipMalloc(&b.p, n));
+    HIPCHK(hipMemcpy(a.p, in, n * 8, hipMemcpyHostToDevice));
+    rd_launch_quantize((const double *)a.p, (uint8_t *)b.p, n, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, b.p, n, hipMemcpyDeviceToHost));
+    return RD_OK;
+}
+
+extern "C" int rd_search(const rd_config *cfg, const uint8_t *quantized, size_t n, int32_t *indices, int cap,
+                         int *count) {
+    if (!count) return fail(RD_ERR_ARG, "null count");
+    rd_devcfg dc;
+    rd_config c2 = *cfg;
+    if (c2.block_size < 32) c2.block_size = 32;  // block size is irrelevant to a bare search
+    c2.block_size -= c2.block_size % 4;
+    int rc = make_devcfg(&c2, &dc);
+    if (rc) return rc;
+    *count = 0;
+    const long span = (long)(dc.P - 1) * dc.S;
+    if ((long)n <= span) return RD_OK;
+    if (!quantized) return fail(RD_ERR_ARG, "null argument");
+    STAGE_PROLOGUE();
+    DevBuf a, w, m, cnt;
+    const uint32_t mcap = (uint32_t)n;
+    HIPCHK(hipMalloc(&a.p, n));
+    HIPCHK(hipMalloc(&w.p, ((n + 31) / 32) * 4));
+    HIPCHK(hipMalloc(&m.p, (size_t)mcap * sizeof(rd_match)));
+    HIPCHK(hipMalloc(&cnt.p, RD_CNT_SLOTS * 4));
+    HIPCHK(hipMemset(cnt.p, 0, RD_CNT_SLOTS * 4));
+    HIPCHK(hipMemcpy(a.p, quantized, n, hipMemcpyHostToDevice));
+    rd_launch_pack_bytes((const uint8_t *)a.p, (uint32_t *)w.p, n, nullptr);
+    rd_launch_search((const uint32_t *)w.p, 0, 1, (long)n, 0, (long)n - 1 - span, dc, (rd_match *)m.p, mcap,
+                     (uint32_t *)cnt.p, nullptr);
+    HIPCHK(hipGetLastError());
+    uint32_t h_cnt[RD_CNT_SLOTS];
+    HIPCHK(hipMemcpy(h_cnt, cnt.p, sizeof h_cnt, hipMemcpyDeviceToHost));
+    const uint32_t nm = std::min(h_cnt[RD_CNT_MATCH], mcap);
+    std::vector<rd_match> ms(nm);
+    if (nm) HIPCHK(hipMemcpy(ms.data(), m.p, (size_t)nm * sizeof(rd_match), hipMemcpyDeviceToHost));
+    const int S = dc.S;
+    std::sort(ms.begin(), ms.end(), [S](const rd_match &x, const rd_match &y) {
+        const int px = x.pos % S, py = y.pos % S;
+        return px != py ? px < py : x.pos < y.pos;
+    });
+    *count = (int)nm;
+    if ((int)nm > cap) return fail(RD_ERR_CAPACITY, "need room for %u indices", nm);
+    for (uint32_t i = 0; i < nm; i++) indices[i] = ms[i].pos;
+    return RD_OK;
+}

@@ -1,0 +1,82 @@
+// rd_internal.h - launch interface between rd_api.hip (host logic, C ABI) and rd_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtldavis_hip.h"
+
+// counters[] slots (device uint32)
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_SLOTS = 8 };
+
+// Geometry of the fused demod kernel
+#define RD_TILE_SAMPLES 2048  // 64 lanes x 32 samples: one wave iteration
+#define RD_TILE_BYTES 4096
+#define RD_INPUT_PAD 8192     // bytes readable past the last stream (ragged last tile)
+
+// One set of streams laid out with a fixed byte stride.
+struct rd_layout {
+    const uint8_t *iq;        // sample 0 of stream 0 (16-byte aligned)
+    size_t stream_stride;     // bytes between streams (multiple of 16)
+    int n_streams;
+    uint32_t n_samples;       // samples per stream handled by this launch
+    int hist_mode;            // 0: zero history before sample 0 (after reset);
+                              // 1: >= 16 samples of raw history precede each stream's sample 0
+    long valid_from;          // first readable sample (0 for hist_mode 0, negative otherwise)
+    uint32_t *bits;           // packed sign bits, word w of stream s at bits[s*bits_stride + w]
+    size_t bits_stride;       // words
+};
+
+struct rd_devcfg {
+    int32_t S, P, K, B, L, PL, nbytes;  // symbol_length, preamble/packet symbols, block, buffer, preamble_length
+    uint64_t pre_mask;                  // bit m = preamble symbol m
+};
+
+struct rd_match {
+    int32_t stream;
+    int32_t pos;  // bit-array coordinate of the first preamble sample
+};
+
+// --- launches (all asynchronous on `st`) ---
+void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st);
+// all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
+// layout does not meet the fast kernel's alignment requirements).
+void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
+                     hipStream_t st);
+// Search positions p in [p_lo, p_hi] of every stream's bit array (bits outside [0, n_bits) are 0).
+void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
+                      const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
+                      hipStream_t st);
+// Slice + RSSI/SNR.  batch_mode = 1: position = absolute sample, calls derived from it
+// (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
+// lay.iq points at the newest block's first sample.
+void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
+                     const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
+                     rd_packet *recs, uint32_t rec_cap, uint32_t *counters, hipStream_t st);
+// d[t0 .. t0+n) of stream `stream` in float64
+void rd_launch_disc(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
+// f[t0 .. t0+n) (interleaved re,im) of stream `stream` in float64
+void rd_launch_filtered(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
+// window <- (window >> shift_bits) with `block` (n_block_bits) appended at the top; window has n_win_bits
+void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_win_bits, const uint32_t *block,
+                             long n_block_bits, hipStream_t st);
+
+// complex128 input path (py:144-150): raw ring of interleaved doubles
+struct rd_cplx_layout {
+    const double *x;   // sample 0 (interleaved re,im)
+    long valid_from;   // first readable sample
+    long n;            // samples
+};
+void rd_launch_cplx_bits(const rd_cplx_layout &lay, uint32_t *bits, hipStream_t st);
+void rd_launch_cplx_disc(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
+void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
+void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
+                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t rec_cap,
+                          uint32_t *counters, hipStream_t st);
+void rd_launch_lut(const uint8_t *in, double *out, size_t n_cplx, hipStream_t st);
+
+// stage kernels on device arrays (float64)
+void rd_launch_rotate(const double *in, double *out, size_t n, hipStream_t st);
+void rd_launch_fir9(const double *in, double *out, size_t n_out, hipStream_t st);
+void rd_launch_discriminate(const double *in, double *out, size_t n_out, hipStream_t st);
+void rd_launch_quantize(const double *in, uint8_t *out, size_t n, hipStream_t st);
+void rd_launch_pack_bytes(const uint8_t *in01, uint32_t *words, size_t n, hipStream_t st);

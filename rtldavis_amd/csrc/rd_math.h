@@ -1,0 +1,319 @@
+// rd_math.h - arithmetic of the IQ -> sign-bit path, shared by the HIP kernels.
+//
+// Every function is `RD_HD` (host + device) so tests can run the very same code on the CPU
+// (tests/host_harness.cpp); the shipped library only ever calls them from device code.
+//
+// Reference stages covered (py = /root/reference/src/rtldavis/dsp.py):
+//   LUT (k-127.4)/127.6 py:26,38-39 ; rotate_fs4 py:46-49 ; fir9 py:56-73 ;
+//   discriminate numerator py:89 ; quantize (sign bit) py:98.
+//
+// Two evaluations of the same sign:
+//   * fast: fp32, on raw byte values k (0..255), scale 127.6 dropped (sign is scale
+//     invariant), centring folded into a per-phase constant, Fs/4 rotation folded into
+//     register naming (swap) and signed tap constants.  Comes with a rigorous error bound
+//     (RD_E_ABS / rd_run_threshold) so a run of samples whose smallest |numerator| is
+//     inside the bound is re-evaluated exactly.
+//   * exact: integers.  x = (5k-637)/638 and taps*1e12 are integers, so the FIR is exact
+//     in int64 (|F| < 6.4e14) and the numerator in __int128.  The sign of the exact value
+//     equals the reference's float64 sign unless |d_ref| is within float64 rounding of 0
+//     (~1e-16 relative); exact zeros follow IEEE signed-zero rules of py:89 (see rd_exact_bit).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RD_HD __host__ __device__ __forceinline__
+#define RD_HDM __host__ __device__ __forceinline__
+#else
+#define RD_HD static inline
+#define RD_HDM inline
+#endif
+
+#define RD_RUN 32          // samples per lane run (one packed output word)
+#define RD_HALO 10         // f[t0-1] needs y[t0-10 .. t0-2]
+#define RD_WIN (RD_RUN + 9) // samples a run reads: t0-10 .. t0+30
+
+// fir9 taps (py:56-69).  Symmetric: c[m] == c[8-m].
+#define RD_C0 0.017682261285
+#define RD_C1 0.048171339939
+#define RD_C2 0.122424706672
+#define RD_C3 0.197408519126
+#define RD_C4 0.228626345955
+// sum_m c_m j^m = 2c0 - 2c2 + c4 (real): response of the filter to the rotated DC term.
+#define RD_CDC (2.0 * RD_C0 - 2.0 * RD_C2 + RD_C4)
+#define RD_DC ((float)(127.4 * RD_CDC))
+
+// ---- rigorous fp32 error bound (units: raw byte values) -------------------------------
+// f_hat = fma chain  acc0 = -D; acc_{k+1} = fma(T_k, s_k, acc_k), k = 0..4, with
+// s_k = w_a +- w_b exact integers (|s_k| <= 510, |w_c| <= 255), T_k = fl32(c_k) * (+-1).
+//   rounding of the 5 fmas : <= 2^-24 * sum_k |partial_k|
+//                            <= 2^-24 * (5*2.44 + 255*(2c0 + (2c0+2c1) + (..+2c2) + (..+2c3) + 1))
+//                            =  2^-24 * (12.2 + 255*2.3152) = 3.60e-5
+//   tap rounding           : <= 2^-24 * sum_k c_k |s_k| <= 2^-24 * 255 = 1.52e-5
+//   rounding of D          : <= 2^-23 (ulp(2.44)/2 = 1.2e-7)
+// total < 5.15e-5; RD_E_ABS adds margin for the second-order terms of the numerator bound.
+#define RD_E_ABS 5.5e-5f
+// With a,b,c,d the true components (|.| <= F + E, F = max |component of f_hat| over the run):
+// |num_hat - num| <= E(|a|+|b|+|c|+|d|) + 2E^2 + 3*2^-24 F^2 <= F*(4E + 2^-22 F) + 6E^2.
+// 6E^2 < 2e-8; the additive 1e-7 and the factor (1 + 2^-20) cover it and the fp32
+// rounding of this expression itself.
+RD_HD float rd_run_threshold(float F) {
+    return (F * (4.0f * RD_E_ABS + 2.3841858e-7f * F) + 1.0e-7f) * 1.000001f;
+}
+
+struct rd_f2 {
+    float x, y;
+};
+
+// Result of the fast evaluation of one run.
+struct rd_run_result {
+    uint32_t word;  // bit r = sign bit of num[t0 + r]   (1 = negative, py:98)
+    float fmax;     // max |component| of f_hat over f[t0-1 .. t0+31]
+    float nmin;     // min |num_hat| over the run
+};
+
+// Signs of rot = j^p applied to (I, Q):  p=0 ( I, Q)  p=1 (-Q, I)  p=2 (-I,-Q)  p=3 ( Q,-I).
+// With w = (I,Q) for even p and (Q,I) for odd p, y = (sr*w.x, si*w.y):
+RD_HD float rd_sr(int p) { return (p == 1 || p == 2) ? -1.0f : 1.0f; }
+RD_HD float rd_si(int p) { return (p == 2 || p == 3) ? -1.0f : 1.0f; }
+
+// Fast fp32 evaluation of one run.  `win` holds the raw bytes of samples t0-10 .. t0+30
+// (2*RD_WIN bytes, I then Q); t0 % 4 == 0 in absolute stream time.  Fully unrolled by the
+// compiler: every phase / tap / sign below is a compile-time constant per unrolled step.
+// `Src::f(i)` returns byte i of that window converted to float (on the device: one
+// v_cvt_f32_ubyteN on a register dword, kept opaque to the optimiser - see rd_kernels.hip).
+struct rd_ptr_src {
+    const uint8_t *p;
+    RD_HDM float f(int i) const { return (float)p[i]; }
+};
+
+// Issue-pipe note (measured on MI355X, tools/ubench): plain fp32 add/sub/mul/fma issue in
+// 2 cycles per wave64, conversions / min / max / bit-field ops in 4, on a second pipe that
+// overlaps with the first when >= 4 waves share a SIMD; packed fp32 takes 4.  The FIR is
+// therefore written as scalar add/sub + fma (18 + 2 ops on the fast pipe per sample) and
+// conversion, guard (max3 / min) and bit insertion (alignbit) ride on the other pipe.
+RD_HD uint32_t rd_bitrev32(uint32_t v) {
+#if defined(__clang__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+
+// (word << 1) | signbit(num)
+RD_HD uint32_t rd_shift_in_sign(uint32_t word, float num) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(word, __builtin_bit_cast(uint32_t, num), 31);
+#else
+    return (word << 1) | (__builtin_bit_cast(uint32_t, num) >> 31);
+#endif
+}
+
+template <class Src>
+RD_HD rd_run_result rd_fast_run(const Src &win) {
+    rd_f2 w[RD_WIN];
+#pragma unroll
+    for (int i = 0; i < RD_WIN; i++) {
+        const int p = (i + 2) & 3;  // phase of sample t0-10+i
+        const float kI = win.f(2 * i), kQ = win.f(2 * i + 1);
+        if (p & 1) { w[i].x = kQ; w[i].y = kI; } else { w[i].x = kI; w[i].y = kQ; }
+    }
+    const float c[5] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4};
+    rd_run_result out;
+    uint32_t word = 0;
+    float fmaxv = 0.0f, nminv = 3.0e38f;
+    rd_f2 prev = {0.0f, 0.0f};
+#pragma unroll
+    for (int r = -1; r < RD_RUN; r++) {
+        // f[t0+r] = sum_m c_m y[t0+r-9+m]; window index of tap m is i = r+1+m
+        const int q = (r + 3 + 4) & 3;  // (t-9) mod 4 for the DC term
+        // (1+j) j^q : q0 (1,1) q1 (-1,1) q2 (-1,-1) q3 (1,-1); acc starts at -D
+        rd_f2 acc;
+        acc.x = (q == 1 || q == 2) ? RD_DC : -RD_DC;
+        acc.y = (q == 2 || q == 3) ? RD_DC : -RD_DC;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ia = r + 1 + k, ib = r + 9 - k;
+            const int pa = (ia + 2) & 3;
+            rd_f2 s;
+            if (k & 1) { s.x = w[ia].x - w[ib].x; s.y = w[ia].y - w[ib].y; }
+            else       { s.x = w[ia].x + w[ib].x; s.y = w[ia].y + w[ib].y; }
+            acc.x = __builtin_fmaf(c[k] * rd_sr(pa), s.x, acc.x);
+            acc.y = __builtin_fmaf(c[k] * rd_si(pa), s.y, acc.y);
+        }
+        {
+            const int ic = r + 5, pc = (ic + 2) & 3;
+            acc.x = __builtin_fmaf(c[4] * rd_sr(pc), w[ic].x, acc.x);
+            acc.y = __builtin_fmaf(c[4] * rd_si(pc), w[ic].y, acc.y);
+        }
+        fmaxv = __builtin_fmaxf(fmaxv, __builtin_fmaxf(__builtin_fabsf(acc.x), __builtin_fabsf(acc.y)));
+        if (r >= 0) {
+            // numerator of py:89: imag_n*real_np - real_n*imag_np, n = f[t-1], np = f[t]
+            const float num = __builtin_fmaf(-prev.x, acc.y, prev.y * acc.x);
+            nminv = __builtin_fminf(nminv, __builtin_fabsf(num));
+            // shift the sign bit in at the bottom (one v_alignbit_b32); reversed after the loop
+            word = rd_shift_in_sign(word, num);
+        }
+        prev = acc;
+    }
+    out.word = rd_bitrev32(word);  // bit r = sign of num[t0+r]
+    out.fmax = fmaxv;
+    out.nmin = nminv;
+    return out;
+}
+
+// ---- exact evaluation ---------------------------------------------------------------
+// taps * 1e12 (exact integers)
+#define RD_T0 17682261285LL
+#define RD_T1 48171339939LL
+#define RD_T2 122424706672LL
+#define RD_T3 197408519126LL
+#define RD_T4 228626345955LL
+
+struct rd_i2 {
+    int64_t x, y;
+};
+
+// Rotated integer sample U*j^p, U = 5k-637 (x = U/638), p = absolute index mod 4.
+RD_HD rd_i2 rd_rot_int(int kI, int kQ, int p) {
+    const int64_t a = 5 * kI - 637, b = 5 * kQ - 637;
+    rd_i2 y;
+    switch (p & 3) {
+        case 0: y.x = a; y.y = b; break;
+        case 1: y.x = -b; y.y = a; break;
+        case 2: y.x = -a; y.y = -b; break;
+        default: y.x = b; y.y = -a; break;
+    }
+    return y;
+}
+
+// Exact FIR output (scaled by 638e12) from nine rotated integer samples y[0..8] (oldest first).
+RD_HD rd_i2 rd_fir_int(const rd_i2 *y) {
+    rd_i2 f;
+    f.x = RD_T0 * (y[0].x + y[8].x) + RD_T1 * (y[1].x + y[7].x) + RD_T2 * (y[2].x + y[6].x) +
+          RD_T3 * (y[3].x + y[5].x) + RD_T4 * y[4].x;
+    f.y = RD_T0 * (y[0].y + y[8].y) + RD_T1 * (y[1].y + y[7].y) + RD_T2 * (y[2].y + y[6].y) +
+          RD_T3 * (y[3].y + y[5].y) + RD_T4 * y[4].y;
+    return f;
+}
+
+// Sign bit of d = (ni*pr - nr*pi)/(|n|^2 + 1e-10) as the reference's float64 code produces it
+// (py:89,98).  Non-zero exact numerator: its sign.  Exact zero: the float64 expression is
+// fl(ni*pr) - fl(nr*pi); with n == 0 (zero history after reset) the products are signed
+// zeros and the difference is -0.0 exactly when pr < 0 and pi > 0 (fixture
+// tests/golden/startup_quadrants.json); otherwise equal products give +0.0.
+RD_HD uint32_t rd_exact_bit(rd_i2 n, rd_i2 np) {
+    const __int128 num = (__int128)n.y * np.x - (__int128)n.x * np.y;
+    if (num < 0) return 1u;
+    if (num > 0) return 0u;
+    if (n.x == 0 && n.y == 0) return (np.x < 0 && np.y > 0) ? 1u : 0u;
+    return 0u;
+}
+
+// Byte fetch used by the exact path: sample index n relative to the stream's first sample.
+// Samples before `valid_from` (<= 0) are the zero history after reset and read as y = 0.
+struct rd_stream_view {
+    const uint8_t *base;  // &iq[0] of sample 0 (bytes before it hold history when valid_from < 0)
+    long valid_from;      // first readable sample index (0: zero history; negative: history bytes)
+    long n;               // number of samples
+};
+
+RD_HD rd_i2 rd_sample_int(const rd_stream_view &v, long n) {
+    if (n < v.valid_from) {
+        rd_i2 z = {0, 0};
+        return z;
+    }
+    const uint8_t *p = v.base + 2 * n;
+    return rd_rot_int(p[0], p[1], (int)(n & 3));
+}
+
+// Exact FIR output f[t] (uses y[t-9 .. t-1]); f[t] for t < valid_from is 0 (py:133 zeros).
+RD_HD rd_i2 rd_f_int(const rd_stream_view &v, long t) {
+    rd_i2 y[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) y[m] = rd_sample_int(v, t - 9 + m);
+    return rd_fir_int(y);
+}
+
+// Exact bits of samples [t0, t0+count), count <= 32, as a packed word (bit r = sample t0+r).
+RD_HD uint32_t rd_exact_run(const rd_stream_view &v, long t0, int count) {
+    rd_i2 y[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) y[m] = rd_sample_int(v, t0 - 10 + m);
+    rd_i2 prev = rd_fir_int(y);  // f[t0-1]
+    uint32_t word = 0;
+    for (int r = 0; r < count; r++) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) y[m] = y[m + 1];
+        y[8] = rd_sample_int(v, t0 + r - 1);
+        const rd_i2 cur = rd_fir_int(y);  // f[t0+r]
+        word |= rd_exact_bit(prev, cur) << r;
+        prev = cur;
+    }
+    return word;
+}
+
+// ---- float64 evaluation (values, not just signs) -------------------------------------
+struct rd_d2 {
+    double x, y;
+};
+
+// py:46-49: x * j^(n mod 4), exact
+RD_HD rd_d2 rd_rot_f64(double a, double b, long n) {
+    rd_d2 y;
+    switch (n & 3) {
+        case 0: y.x = a; y.y = b; break;
+        case 1: y.x = -b; y.y = a; break;
+        case 2: y.x = -a; y.y = -b; break;
+        default: y.x = b; y.y = -a; break;
+    }
+    return y;
+}
+
+RD_HD rd_d2 rd_sample_f64(const rd_stream_view &v, long n) {
+    rd_d2 y = {0.0, 0.0};
+    if (n < v.valid_from) return y;
+    const uint8_t *p = v.base + 2 * n;
+    return rd_rot_f64(((double)p[0] - 127.4) / 127.6, ((double)p[1] - 127.4) / 127.6, n);  // py:26
+}
+
+// complex128 input (py:144-150): interleaved re,im doubles
+struct rd_cplx_view {
+    const double *base;  // sample 0
+    long valid_from;
+    long n;
+};
+
+RD_HD rd_d2 rd_sample_f64(const rd_cplx_view &v, long n) {
+    rd_d2 y = {0.0, 0.0};
+    if (n < v.valid_from) return y;
+    return rd_rot_f64(v.base[2 * n], v.base[2 * n + 1], n);
+}
+
+// float64 fir9 output f[t] = sum_m c_m y[t-9+m], products summed in tap order m = 0..8
+// (np.convolve's own order is unspecified; agreement is ~1 ulp).  Compiled with
+// -ffp-contract=off so no fma contraction changes the rounding.  f[t] before the first
+// readable sample is the zero state of py:133.
+template <class View>
+RD_HD rd_d2 rd_f_f64(const View &v, long t) {
+    const double c[9] = {RD_C0, RD_C1, RD_C2, RD_C3, RD_C4, RD_C3, RD_C2, RD_C1, RD_C0};
+    rd_d2 f = {0.0, 0.0};
+    if (t < v.valid_from) return f;
+#pragma unroll
+    for (int m = 0; m < 9; m++) {
+        const rd_d2 y = rd_sample_f64(v, t - 9 + m);
+        f.x += c[m] * y.x;
+        f.y += c[m] * y.y;
+    }
+    return f;
+}
+
+// py:80-90
+RD_HD double rd_disc_f64(rd_d2 n, rd_d2 np) {
+    return (n.y * np.x - n.x * np.y) / (n.x * n.x + n.y * n.y + 1e-10);
+}
+
+RD_HD uint32_t rd_signbit_f64(double d) { return (uint32_t)(__builtin_bit_cast(uint64_t, d) >> 63); }

@@ -1,0 +1,216 @@
+"""Drop-in mirror of rtldavis's ``dsp`` module backed by hand-written HIP kernels (gfx950).
+
+Same names, argument meaning and error behaviour as /root/reference/src/rtldavis/dsp.py so
+``protocol.Parser`` and ``worker.worker_main`` run unchanged on top of it:
+
+    Packet, ByteToCmplxLUT, rotate_fs4, fir9, discriminate, quantize, PacketConfig, Demodulator
+
+Every function executes on the GPU through the C ABI of librtldavis_hip.so; nothing here
+computes the path on the CPU.  The HIP context is created lazily by the first
+``demodulate()`` (not by ``__init__``) because the reference builds one Demodulator in
+the parent and one in a ``fork``ed worker (runners/rtlsdr.py:30, worker.py:29).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class Packet:
+    """dsp.Packet (dsp.py:12-17)."""
+
+    index: int
+    data: np.ndarray
+    rssi: float
+    snr: float
+
+
+def _c128(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+class ByteToCmplxLUT:
+    """dsp.ByteToCmplxLUT (dsp.py:20-39): (k - 127.4) / 127.6 per byte, on the device."""
+
+    def __init__(self) -> None:
+        # kept for attribute compatibility (dsp.py:26); execute() does not read it
+        self.lut: np.ndarray = (np.arange(256, dtype=np.float64) - 127.4) / 127.6
+
+    def execute(self, in_bytes: np.ndarray, out_cmplx: np.ndarray) -> None:
+        if in_bytes.size != out_cmplx.size * 2:
+            logger.error(
+                f"Incompatible array sizes: in_bytes.size={in_bytes.size}, out_cmplx.size={out_cmplx.size}"
+            )
+            raise ValueError("Incompatible array sizes")
+        src = np.ascontiguousarray(in_bytes, dtype=np.uint8)
+        tmp = np.empty(out_cmplx.size, dtype=np.complex128)
+        _lib.check(_lib.lib().rd_lut_execute(src.ctypes.data, src.size, tmp.ctypes.data, tmp.size))
+        out_cmplx[...] = tmp
+
+
+def rotate_fs4(in_cmplx: np.ndarray, out_cmplx: np.ndarray) -> None:
+    """dsp.rotate_fs4 (dsp.py:42-49).  in and out may be the same array."""
+    src = _c128(in_cmplx)
+    tmp = np.empty(src.size, dtype=np.complex128)
+    _lib.check(_lib.lib().rd_rotate_fs4(src.ctypes.data, tmp.ctypes.data, src.size))
+    out_cmplx[...] = tmp
+
+
+def fir9(in_cmplx: np.ndarray, out_cmplx: np.ndarray) -> None:
+    """dsp.fir9 (dsp.py:52-73): the first out.size 'valid' outputs of the 9-tap filter."""
+    src = _c128(in_cmplx)
+    n = out_cmplx.size
+    tmp = np.empty(n, dtype=np.complex128)
+    _lib.check(_lib.lib().rd_fir9(src.ctypes.data, src.size, tmp.ctypes.data, n))
+    out_cmplx[:] = tmp
+
+
+def discriminate(in_cmplx: np.ndarray, out_float: np.ndarray) -> None:
+    """dsp.discriminate (dsp.py:76-90)."""
+    src = _c128(in_cmplx)
+    n = max(src.size - 1, 0)
+    tmp = np.empty(n, dtype=np.float64)
+    _lib.check(_lib.lib().rd_discriminate(src.ctypes.data, src.size, tmp.ctypes.data, n))
+    out_float[:n] = tmp
+
+
+def quantize(in_float: np.ndarray, out_byte: np.ndarray) -> None:
+    """dsp.quantize (dsp.py:93-98): IEEE-754 sign bit of each value."""
+    src = np.ascontiguousarray(in_float, dtype=np.float64)
+    tmp = np.empty(src.size, dtype=np.uint8)
+    _lib.check(_lib.lib().rd_quantize(src.ctypes.data, tmp.ctypes.data, src.size))
+    out_byte[: src.size] = tmp
+
+
+class PacketConfig:
+    """dsp.PacketConfig (dsp.py:101-125), attribute for attribute."""
+
+    def __init__(self, bit_rate: int, symbol_length: int, preamble_symbols: int, packet_symbols: int,
+                 preamble: str, block_size: int = 512) -> None:
+        self.bit_rate = bit_rate
+        self.symbol_length = symbol_length
+        self.preamble_symbols = preamble_symbols
+        self.packet_symbols = packet_symbols
+        self.preamble = preamble
+        self.preamble_bytes = np.array([int(b) for b in preamble], dtype=np.uint8)
+        self.preamble_str = self.preamble_bytes.tobytes()
+        self.sample_rate = self.bit_rate * self.symbol_length
+        self.block_size = block_size
+        self.block_size2 = self.block_size * 2
+        self.preamble_length = self.preamble_symbols * self.symbol_length
+        self.packet_length = self.packet_symbols * self.symbol_length
+        self.buffer_length = (self.packet_length // self.block_size + 2) * self.block_size
+
+    def _c(self) -> _lib.RdConfig:
+        return _lib.make_config(self.bit_rate, self.symbol_length, self.preamble_symbols, self.packet_symbols,
+                                self.preamble, self.block_size)
+
+
+def _packets_from(recs, n: int) -> List[Packet]:
+    out = []
+    for i in range(n):
+        r = recs[i]
+        data = np.frombuffer(bytes(r.data[: r.nbytes]), dtype=np.uint8)  # read-only, like dsp.py:241
+        out.append(Packet(index=int(r.index), data=data, rssi=float(r.rssi), snr=float(r.snr)))
+    return out
+
+
+class Demodulator:
+    """dsp.Demodulator (dsp.py:128-253) on the GPU.
+
+    ``demodulate(block)`` takes exactly one block (uint8[2*block_size] interleaved I,Q or
+    complex[block_size]) and returns the reference's ``List[Packet]``.  ``discriminated``,
+    ``filtered`` and ``quantized`` are materialised from device state on access.
+    """
+
+    def __init__(self, cfg: PacketConfig) -> None:
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._pid = os.getpid()
+        _lib.check(_lib.lib().rd_create(C.byref(cfg._c()), C.byref(self._h)))  # host state only
+        self._cap = 64
+        self._recs = (_lib.RdPacket * self._cap)()
+        self.byte_to_cmplx = ByteToCmplxLUT()
+
+    def __del__(self):
+        try:
+            if self._h and self._pid == os.getpid():
+                _lib.lib().rd_destroy(self._h)
+        except Exception:
+            pass
+
+    def _handle(self):
+        if self._pid != os.getpid():
+            # forked copy of a handle created in the parent: it holds no device state yet
+            # (lazy init), so it is safe to keep using it in the child.
+            self._pid = os.getpid()
+        return self._h
+
+    def demodulate(self, input_data: np.ndarray) -> List[Packet]:
+        bs = self.cfg.block_size
+        if np.iscomplexobj(input_data):
+            if input_data.size != bs:
+                logger.error(f"Incompatible array sizes: input_data.size={input_data.size}, dest.size={bs}")
+                raise ValueError("Incompatible array sizes")
+            buf = _c128(input_data)
+            count, is_c = buf.size, 1
+        else:
+            if input_data.size != 2 * bs:
+                logger.error(f"Incompatible array sizes: in_bytes.size={input_data.size}, out_cmplx.size={bs}")
+                raise ValueError("Incompatible array sizes")
+            buf = np.ascontiguousarray(input_data, dtype=np.uint8)
+            count, is_c = buf.size, 0
+        n = C.c_int(0)
+        L = _lib.lib()
+        rc = L.rd_demod_block(self._handle(), buf.ctypes.data, count, is_c, self._recs, self._cap, C.byref(n))
+        if rc == _lib.RD_ERR_CAPACITY:
+            # the block is already consumed; results stay on the device only until the next
+            # call, so this cannot be retried - size the list for the worst case up front
+            raise BufferError(_lib.last_error())
+        _lib.check(rc)
+        return _packets_from(self._recs, n.value)
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib().rd_reset(self._handle()))
+
+    @property
+    def discriminated(self) -> np.ndarray:
+        out = np.empty(2 * self.cfg.block_size, dtype=np.float64)
+        _lib.check(_lib.lib().rd_copy_discriminated(self._handle(), out.ctypes.data, out.size))
+        return out
+
+    @property
+    def filtered(self) -> np.ndarray:
+        out = np.empty(self.cfg.block_size + 1, dtype=np.complex128)
+        _lib.check(_lib.lib().rd_copy_filtered(self._handle(), out.ctypes.data, out.size))
+        return out
+
+    @property
+    def quantized(self) -> np.ndarray:
+        out = np.empty(self.cfg.buffer_length, dtype=np.uint8)
+        _lib.check(_lib.lib().rd_copy_quantized(self._handle(), out.ctypes.data, out.size))
+        return out
+
+    def _search(self) -> List[int]:
+        """dsp.Demodulator._search (dsp.py:171-188) over the current quantized buffer."""
+        return search(self.quantized, self.cfg)
+
+
+def search(quantized: np.ndarray, cfg: PacketConfig) -> List[int]:
+    """Preamble search over a 0/1-per-byte buffer in the reference's order (dsp.py:171-188,
+    dsp/dsp.go:105-131)."""
+    q = np.ascontiguousarray(quantized, dtype=np.uint8)
+    idx = np.empty(max(q.size, 1), dtype=np.int32)
+    n = C.c_int(0)
+    _lib.check(_lib.lib().rd_search(C.byref(cfg._c()), q.ctypes.data, q.size, idx.ctypes.data, idx.size, C.byref(n)))
+    return [int(v) for v in idx[: n.value]]

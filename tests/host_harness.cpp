@@ -1,0 +1,54 @@
+// CPU harness around rtldavis_amd/csrc/rd_math.h.  TEST INFRASTRUCTURE ONLY: it lets the
+// CPU test-suite run the exact arithmetic the HIP kernels execute (same inline functions,
+// same fp32 fma sequence) against the oracle without a GPU.  Nothing in the product links it.
+#include <cstring>
+#include <vector>
+
+#include "../rtldavis_amd/csrc/rd_math.h"
+
+extern "C" {
+
+// Fast path over a whole stream from reset.  words[n/32]; flagged[n/32] = 1 where the run
+// must be re-evaluated exactly (guard band, or run 0 whose history is the zero state).
+long hh_fast_stream(const uint8_t *iq, long n, uint32_t *words, uint8_t *flagged) {
+    long nflag = 0;
+    for (long t0 = 0; t0 + RD_RUN <= n; t0 += RD_RUN) {
+        uint8_t win[2 * RD_WIN];
+        for (int i = 0; i < RD_WIN; i++) {
+            long s = t0 - RD_HALO + i;
+            win[2 * i] = s >= 0 ? iq[2 * s] : 0;
+            win[2 * i + 1] = s >= 0 ? iq[2 * s + 1] : 0;
+        }
+        rd_ptr_src src = {win};
+        rd_run_result r = rd_fast_run(src);
+        words[t0 / RD_RUN] = r.word;
+        uint8_t f = (t0 == 0) || !(r.nmin > rd_run_threshold(r.fmax));
+        flagged[t0 / RD_RUN] = f;
+        nflag += f;
+    }
+    return nflag;
+}
+
+void hh_exact_stream(const uint8_t *iq, long n, uint32_t *words) {
+    rd_stream_view v = {iq, 0, n};
+    for (long t0 = 0; t0 < n; t0 += RD_RUN) {
+        int cnt = (int)(n - t0 < RD_RUN ? n - t0 : RD_RUN);
+        words[t0 / RD_RUN] = rd_exact_run(v, t0, cnt);
+    }
+}
+
+// float64 stages: f[-1..n-1] interleaved (2(n+1) doubles) and d[0..n-1].
+void hh_f64_stream(const uint8_t *iq, long n, double *filt, double *disc) {
+    rd_stream_view v = {iq, 0, n};
+    rd_d2 prev = rd_f_f64(v, -1);
+    filt[0] = prev.x; filt[1] = prev.y;
+    for (long t = 0; t < n; t++) {
+        rd_d2 cur = rd_f_f64(v, t);
+        filt[2 * (t + 1)] = cur.x; filt[2 * (t + 1) + 1] = cur.y;
+        disc[t] = rd_disc_f64(prev, cur);
+        prev = cur;
+    }
+}
+
+float hh_threshold(float F) { return rd_run_threshold(F); }
+}

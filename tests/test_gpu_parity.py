@@ -1,0 +1,348 @@
+"""GPU parity tests (MI355X): the HIP path, called through the C ABI, against the golden
+fixtures generated from the real reference and against the C oracle on the same inputs."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_calls_equal, dense_calls, load_json, load_npz
+from rtldavis_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    from rtldavis_amd import _lib, dsp as d
+    assert _lib.lib().rd_device_count() > 0, "no HIP device: the GPU tests need an MI355X"
+    return d
+
+
+@pytest.fixture(scope="module")
+def batchmod():
+    from rtldavis_amd import batch
+    return batch
+
+
+def prod_cfg(dsp, **kw):
+    args = dict(bit_rate=19200, symbol_length=14, preamble_symbols=16, packet_symbols=80,
+                preamble="1100101110001001", block_size=8192)
+    args.update(kw)
+    return dsp.PacketConfig(**args)
+
+
+def run_streaming(dem, raw=None, cplx=None):
+    B = dem.cfg.block_size
+    calls = []
+    n = raw.size // 2 if cplx is None else cplx.size
+    for b in range(n // B):
+        blk = raw[2 * B * b: 2 * B * (b + 1)] if cplx is None else cplx[B * b: B * (b + 1)]
+        calls.append(dem.demodulate(blk))
+    return calls
+
+
+# ---------------------------------------------------------------- batch path (configs 2,3)
+def test_batch_streams_bits_and_packets(dsp, batchmod, golden_streams):
+    seeds = list(range(8))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    res = bd.demodulate(raw)
+    full = load_npz("streams_bits.npz")
+    for i, seed in enumerate(seeds):
+        g = golden_streams[str(seed)]
+        assert sha(raw[i]) == g["raw_sha256"]
+        bits = bd.bits(i)
+        assert sha(bits) == g["bits_sha256"], f"seed {seed}: packed bits differ from the reference"
+        if seed < 4:
+            assert np.array_equal(bits, full[f"seed{seed}"])
+        assert_calls_equal(res[i], dense_calls(g["calls"], synth.BLOCKS_PER_STREAM))
+    c = bd.counters()
+    assert 0 < c["fixup_runs"] < 0.1 * len(seeds) * 8448
+
+
+def test_batch_matches_c_oracle_51_channels(dsp, batchmod):
+    """Config 3: 51 hop channels in one launch; checked against the C oracle run here."""
+    from oracle import c_oracle as CO
+    seeds = list(range(100, 151))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    res = bd.demodulate(raw)
+    want, wbits = CO.demod_batch(raw, CO.make_cfg(), threads=8, want_bits=True)
+    for i in range(len(seeds)):
+        assert np.array_equal(bd.bits(i), wbits[i]), f"stream {i}"
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+        exp = [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
+        assert got == exp
+        for (c, ps), w in zip([(c, p) for c, pl in enumerate(res[i]) for p in pl], want[i]):
+            assert abs(ps.rssi - w.rssi) < 1e-3 and abs(ps.snr - w.snr) < 1e-3
+        true = [bytes(p.data).hex() for pl in res[i] for p in pl if bytes(p.data).hex() == synth.payload_of(seeds[i])]
+        assert len(true) >= 1
+
+
+def test_batch_discriminated_and_freq_error(dsp, batchmod, golden_streams):
+    import math
+    raw = synth.synth_streams([0])
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), 1, synth.BLOCKS_PER_STREAM)
+    bd.demodulate(raw)
+    g = golden_streams["0"]["parse"]["21"][0]
+    # call 21, index 5502 -> absolute sample 20*8192 + 5502
+    t0 = 20 * 8192 + g["index"]
+    d = bd.discriminated(0, t0, 224)
+    fe = -int((np.mean(d) * 268800.0) / (2 * math.pi))
+    assert abs(fe - g["freq_err"]) <= 1
+    st = load_npz("burst_seed0_b20_22_state.npz")
+    ref = st["disc_all"]  # d over blocks 20..22 of seed 0 (cut stream: first samples differ by history)
+    got = bd.discriminated(0, 20 * 8192 + 64, 3 * 8192 - 64)
+    r = ref[64:]
+    assert np.all(np.abs(got - r) <= 1e-5 * np.maximum(1, np.abs(r)))
+
+
+def test_batch_small_and_ragged_shapes(dsp, batchmod):
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(7)
+    for B, nb, ns in [(512, 3, 5), (1024, 1, 3), (8192, 1, 1), (96, 40, 2), (36, 70, 3)]:
+        raw = rng.integers(0, 256, size=(ns, 2 * B * nb), dtype=np.uint8)
+        # plant the sync word so the search has something to find
+        cfg = prod_cfg(dsp, block_size=B)
+        bd = batchmod.BatchDemodulator(cfg, ns, nb)
+        res = bd.demodulate(raw)
+        want, wbits = CO.demod_batch(raw, CO.make_cfg(block_size=B), threads=2, want_bits=True)
+        for i in range(ns):
+            assert np.array_equal(bd.bits(i), wbits[i]), (B, nb, i)
+            got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+            assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]], (B, nb, i)
+
+
+def test_batch_degenerate_inputs_take_the_exact_path(dsp, batchmod):
+    """Low-amplitude and saturated inputs put most runs inside the guard band: the guard
+    list overflows and every run is re-evaluated exactly.  Bits must still match."""
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(11)
+    B, nb = 8192, 4
+    raw = np.stack([
+        rng.integers(126, 130, size=2 * B * nb, dtype=np.uint8),
+        rng.integers(127, 129, size=2 * B * nb, dtype=np.uint8),
+        rng.choice(np.array([0, 255], np.uint8), size=2 * B * nb),
+        rng.integers(0, 256, size=2 * B * nb, dtype=np.uint8),
+    ])
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), raw.shape[0], nb)
+    res = bd.demodulate(raw)
+    want, wbits = CO.demod_batch(raw, CO.make_cfg(), threads=4, want_bits=True)
+    for i in range(raw.shape[0]):
+        assert np.array_equal(bd.bits(i), wbits[i]), i
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+        assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
+
+
+def test_batch_replicas_are_identical_property(dsp, batchmod, golden_streams):
+    """Size-independent property at a larger size: 512 streams tiled from 8 unique ones give
+    512 bitstreams whose hashes are the 8 golden ones, and the same packets."""
+    uniq = synth.synth_streams(range(8))
+    raw = np.tile(uniq, (64, 1))
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), raw.shape[0], synth.BLOCKS_PER_STREAM)
+    bd.upload(raw)
+    bd.run()
+    recs = bd.records()
+    per = {}
+    for s, c, p in recs:
+        per.setdefault(s, []).append((c, p.index, bytes(p.data).hex()))
+    for s in range(raw.shape[0]):
+        g = golden_streams[str(s % 8)]
+        want = [(int(c), p["index"], p["data"]) for c, ps in sorted(g["calls"].items(), key=lambda kv: int(kv[0]))
+                for p in ps]
+        assert per.get(s, []) == want, s
+    for s in (0, 9, 255, 511):
+        assert sha(bd.bits(s)) == golden_streams[str(s % 8)]["bits_sha256"]
+
+
+# ---------------------------------------------------------------- streaming Demodulator
+def test_demodulator_burst_config1(dsp):
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    g = load_json("burst_seed0_b20_22.json")
+    st = load_npz("burst_seed0_b20_22_state.npz")
+    dem = dsp.Demodulator(prod_cfg(dsp))
+    assert np.all(dem.discriminated == 0) and np.all(dem.quantized == 0)
+    calls = run_streaming(dem, raw)
+    assert_calls_equal(calls, g["calls"])
+    assert bytes(calls[1][0].data).hex() == "cb890520ac8bd4000e5c"
+    assert not calls[1][0].data.flags.writeable
+    q = dem.quantized
+    assert np.array_equal(np.packbits(q, bitorder="little"), st["quantized"])
+    np.testing.assert_allclose(dem.filtered, st["filtered"], rtol=0, atol=1e-13)
+    ref = st["discriminated"]
+    assert np.all(np.abs(dem.discriminated - ref) <= 1e-5 * np.maximum(1, np.abs(ref)))
+    dem.reset()
+    assert_calls_equal(run_streaming(dem, raw), g["calls"])
+
+
+def test_demodulator_freq_error_like_parser(dsp):
+    """protocol.Parser.parse reads demodulator.discriminated right after the call (protocol.py:304-311)."""
+    import math
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    g = load_json("burst_seed0_b20_22.json")
+    cfg = prod_cfg(dsp)
+    dem = dsp.Demodulator(cfg)
+    dem.demodulate(raw[:16384])
+    pk = dem.demodulate(raw[16384:32768])
+    idx = pk[0].index
+    mean = np.mean(dem.discriminated[idx: idx + cfg.preamble_length])
+    assert -int((mean * float(cfg.sample_rate)) / (2 * math.pi)) == g["parse"][1][0]["freq_err"]
+
+
+def test_demodulator_block512_and_state(dsp):
+    z = load_npz("b512_stages.npz")
+    g = load_json("b512_calls.json")
+    cfg = dsp.PacketConfig(**g["config"])
+    dem = dsp.Demodulator(cfg)
+    calls = run_streaming(dem, z["raw"])
+    assert_calls_equal(calls, g["calls"])
+    assert np.array_equal(dem.quantized, z["last_quantized"])
+    np.testing.assert_allclose(dem.filtered, z["last_filtered"], rtol=0, atol=1e-13)
+    ref = z["last_discriminated"]
+    assert np.all(np.abs(dem.discriminated - ref) <= 1e-5 * np.maximum(1, np.abs(ref)))
+
+
+def test_demodulator_edge_q_equals_block_size(dsp):
+    g = load_json("edge_q_eq_B.json")
+    raw = synth.synth_stream(g["seed"], n_samples=g["n_samples"], start=g["start"])
+    calls = run_streaming(dsp.Demodulator(prod_cfg(dsp)), raw)
+    assert_calls_equal(calls, g["calls"])
+    idx = [(b, p.index) for b, c in enumerate(calls) for p in c]
+    assert (2, 8192) in idx and (3, 0) in idx
+
+
+def test_batch_edge_q_equals_block_size(dsp, batchmod):
+    g = load_json("edge_q_eq_B.json")
+    raw = synth.synth_stream(g["seed"], n_samples=g["n_samples"], start=g["start"])
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), 1, g["n_samples"] // 8192)
+    res = bd.demodulate(raw[None, :])
+    assert_calls_equal(res[0], g["calls"])
+    assert sha(bd.bits(0)) == g["bits_sha256"]
+
+
+def test_alt_symbol_length(dsp, batchmod):
+    g = load_json("alt_s8_b1024.json")
+    cfg = dsp.PacketConfig(**g["config"])
+    raw = synth.synth_stream(g["seed"], n_samples=g["n_samples"], symbol_length=8, margin=g["margin"])
+    assert_calls_equal(run_streaming(dsp.Demodulator(cfg), raw), g["calls"])
+    bd = batchmod.BatchDemodulator(cfg, 1, g["n_samples"] // 1024)
+    res = bd.demodulate(raw[None, :])
+    assert_calls_equal(res[0], g["calls"])
+    assert np.array_equal(bd.bits(0), load_npz("alt_s8_b1024_bits.npz")["bits"])
+
+
+def test_complex_input_branch(dsp):
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    cplx = (raw[0::2].astype(np.float64) - 127.5) / 127.5 + 1j * (raw[1::2].astype(np.float64) - 127.5) / 127.5
+    g = load_json("complex_input.json")
+    st = load_npz("complex_input_state.npz")
+    dem = dsp.Demodulator(prod_cfg(dsp))
+    calls = run_streaming(dem, cplx=cplx)
+    assert_calls_equal(calls, g["calls"])
+    assert [p.index for p in calls[1]] == [5502, 536]  # phase-major order
+    np.testing.assert_allclose(dem.filtered, st["filtered"], rtol=0, atol=1e-13)
+    ref = st["discriminated"]
+    assert np.all(np.abs(dem.discriminated - ref) <= 1e-5 * np.maximum(1, np.abs(ref)))
+    # complex64 input is accepted like any complex array (np.iscomplexobj, dsp.py:144)
+    dem.reset()
+    calls32 = run_streaming(dem, cplx=cplx.astype(np.complex64))
+    assert [bytes(p.data).hex() for c in calls32 for p in c][0] == "cb890520ac8bd4000e5c"
+
+
+def test_mixed_uint8_then_complex_keeps_history(dsp):
+    """uint8 blocks then the same samples as complex: identical to all-uint8 (the reference
+    converts bytes with the LUT and keeps complex history, dsp.py:150-152)."""
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    g = load_json("burst_seed0_b20_22.json")
+    lut = (np.arange(256, dtype=np.float64) - 127.4) / 127.6
+    cplx = lut[raw[0::2]] + 1j * lut[raw[1::2]]
+    dem = dsp.Demodulator(prod_cfg(dsp))
+    calls = [dem.demodulate(raw[:16384]), dem.demodulate(cplx[8192:16384]), dem.demodulate(raw[32768:])]
+    assert_calls_equal(calls, g["calls"])
+
+
+def test_startup_signed_zero_quadrants(dsp):
+    g = load_json("startup_quadrants.json")
+    cfg = prod_cfg(dsp, block_size=512)
+    for name, rec in g.items():
+        raw = np.frombuffer(bytes.fromhex(rec["raw"]), dtype=np.uint8)
+        dem = dsp.Demodulator(cfg)
+        dem.demodulate(raw)
+        bits = np.packbits(dem.quantized[-512:], bitorder="little")
+        assert bits.tobytes().hex() == rec["bits"], name
+
+
+def test_errors_like_reference(dsp):
+    dem = dsp.Demodulator(prod_cfg(dsp))
+    with pytest.raises(ValueError, match="Incompatible array sizes"):
+        dem.demodulate(np.zeros(100, dtype=np.uint8))
+    with pytest.raises(ValueError, match="Incompatible array sizes"):
+        dem.demodulate(np.zeros(100, dtype=np.complex128))
+    with pytest.raises(ValueError, match="Incompatible array sizes"):
+        dsp.ByteToCmplxLUT().execute(np.zeros(10, np.uint8), np.zeros(4, np.complex128))
+    # a non-contiguous slice is accepted
+    raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+    wide = np.zeros(2 * 16384, dtype=np.uint8)
+    wide[::2] = raw[:16384]
+    assert dem.demodulate(wide[::2]) == []
+
+
+# ---------------------------------------------------------------- stage functions
+def test_stage_functions_against_fixture(dsp):
+    z = load_npz("b512_stages.npz")
+    raw = z["raw"]
+    x = np.zeros(512, dtype=np.complex128)
+    dsp.ByteToCmplxLUT().execute(raw[-1024:], x)
+    np.testing.assert_array_equal(x, z["last_raw_samples"])
+    y = np.empty_like(x)
+    dsp.rotate_fs4(x, y)
+    np.testing.assert_array_equal(y, z["last_iq"][9:])
+    dsp.rotate_fs4(x, x)  # in place, like dsp.py:160
+    np.testing.assert_array_equal(x, z["last_iq"][9:])
+    f = np.zeros(513, dtype=np.complex128)
+    dsp.fir9(z["last_iq"], f[1:])
+    np.testing.assert_allclose(f[1:], z["last_filtered"][1:], rtol=0, atol=1e-14)
+    d = np.zeros(512)
+    dsp.discriminate(z["last_filtered"], d)
+    ref = z["last_discriminated"][512:]
+    assert np.all(np.abs(d - ref) <= 1e-9 * np.maximum(1, np.abs(ref)))
+    q = np.zeros(512, dtype=np.uint8)
+    dsp.quantize(z["last_discriminated"][512:], q)
+    np.testing.assert_array_equal(q, z["last_quantized"][-512:])
+    assert dsp.search(z["last_quantized"], dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 512)) == \
+        [i for i in _ref_search(z["last_quantized"], 14, "1100101110001001")]
+
+
+def _ref_search(q, S, pre):
+    from oracle import dsp_oracle as O
+    return O.search(q, O.OracleConfig(symbol_length=S, preamble=pre, preamble_symbols=len(pre)))
+
+
+def test_quantize_reference_tests(dsp):
+    """The reference's tests/test_dsp.py:4-33, verbatim in behaviour."""
+    in_float = np.array([-5.0, 5.0, -0.1, 0.1, 0.0])
+    out_byte = np.zeros(len(in_float), dtype=np.uint8)
+    dsp.quantize(in_float, out_byte)
+    assert out_byte.tolist() == [1, 0, 1, 0, 0]
+    rng = np.random.default_rng(42)
+    in_float = rng.uniform(-10, 10, 1000)
+    out_byte = np.zeros(len(in_float), dtype=np.uint8)
+    dsp.quantize(in_float, out_byte)
+    assert np.array_equal(out_byte, (in_float < 0).astype(np.uint8))
+    z = np.zeros(1, np.uint8)
+    dsp.quantize(np.array([-0.0]), z)
+    assert z[0] == 1
+
+
+def test_search_many_matches_order(dsp):
+    """A buffer full of preambles: order must be phase-major (dsp.py:175-186)."""
+    pre = "1100101110001001"
+    cfg = dsp.PacketConfig(19200, 14, 16, 80, pre, 512)
+    q = np.zeros(4096, dtype=np.uint8)
+    for start in (5, 19, 300, 301, 1000, 2000 + 13, 3500):
+        q[start: start + 16 * 14: 14] = [int(c) for c in pre]
+    assert dsp.search(q, cfg) == _ref_search(q, 14, pre)
