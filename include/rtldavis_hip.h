@@ -56,13 +56,15 @@ typedef struct rd_packet {
     double snr;
 } rd_packet;
 
-/* Per-launch timing of the kernels of one rd_batch_run (HIP events on the run's stream). */
+/* Mean per-launch duration of the kernels of the rd_batch_run calls made since timing was
+ * enabled or last read (HIP events recorded on each run's stream). */
 typedef struct rd_timing {
     float demod_ms;  /* fused LUT+rotate+FIR+discriminator-sign+pack kernel */
     float fixup_ms;  /* exact re-evaluation of guard-band samples */
     float search_ms; /* preamble search */
     float slice_ms;  /* slice + RSSI/SNR */
     float total_ms;
+    int32_t runs;    /* runs averaged */
 } rd_timing;
 
 const char *rd_last_error(void);
@@ -122,11 +124,13 @@ int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n);
 int rd_batch_copy_bits(rd_batch *b, int stream, uint8_t *out, size_t nbytes);
 /* Full-precision discriminator output d[t0 .. t0+n) of one stream (py:76-90), float64. */
 int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out, size_t n);
-/* Enable per-kernel HIP-event timing (adds events to the stream) and read the last run's. */
+/* Enable per-kernel HIP-event timing (five events per run on the run's stream); get_timing
+ * synchronises, returns the mean over the runs recorded so far and starts a new window. */
 int rd_batch_set_timing(rd_batch *b, int enabled);
 int rd_batch_get_timing(rd_batch *b, rd_timing *out);
-/* Counters of the last run: guard-band runs re-evaluated exactly, raw preamble matches. */
-int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t *matches);
+/* Counters of the last run: 8-sample groups re-evaluated exactly (guard band), raw preamble
+ * matches. */
+int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_groups, uint64_t *matches);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage functions on host arrays (caller-allocated out-params, like the reference's).

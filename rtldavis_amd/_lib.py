@@ -32,7 +32,7 @@ class RdPacket(C.Structure):
 
 class RdTiming(C.Structure):
     _fields_ = [("demod_ms", C.c_float), ("fixup_ms", C.c_float), ("search_ms", C.c_float),
-                ("slice_ms", C.c_float), ("total_ms", C.c_float)]
+                ("slice_ms", C.c_float), ("total_ms", C.c_float), ("runs", C.c_int32)]
 
 
 # name -> (restype, argtypes); exactly the functions include/rtldavis_hip.h declares

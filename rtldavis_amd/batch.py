@@ -13,6 +13,11 @@ from . import _lib
 from .dsp import Packet, PacketConfig
 
 
+RD_PACKET_DTYPE = np.dtype([("stream", "<i4"), ("call", "<i4"), ("index", "<i4"), ("nbytes", "<i4"),
+                            ("data", "u1", (_lib.RD_MAX_PKT_BYTES,)), ("rssi", "<f8"), ("snr", "<f8")])
+assert RD_PACKET_DTYPE.itemsize == C.sizeof(_lib.RdPacket)
+
+
 class BatchDemodulator:
     def __init__(self, cfg: PacketConfig, n_streams: int, n_blocks: int, device: Optional[int] = None) -> None:
         self.cfg = cfg
@@ -63,11 +68,13 @@ class BatchDemodulator:
     def counters(self) -> dict:
         f, m = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().rd_batch_get_counters(self._b, C.byref(f), C.byref(m)))
-        return {"fixup_runs": f.value, "matches": m.value}
+        return {"fixup_groups": f.value, "matches": m.value}
 
     # ---- results --------------------------------------------------------------------------
-    def records(self):
-        """Flat list of (stream, call, Packet) in (stream, call, reference order)."""
+    def results(self) -> np.ndarray:
+        """All packets of the last run as one structured array (fields of rd_packet: stream,
+        call, index, nbytes, data[32], rssi, snr), sorted by (stream, call, reference order).
+        The array is a view of a buffer that the next results() call overwrites."""
         L = _lib.lib()
         n = C.c_int(0)
         if self._recs is None:
@@ -79,11 +86,15 @@ class BatchDemodulator:
             self._recs = (_lib.RdPacket * self._cap)()
             rc = L.rd_batch_results(self._b, self._recs, self._cap, C.byref(n))
         _lib.check(rc)
+        return np.frombuffer(self._recs, dtype=RD_PACKET_DTYPE, count=n.value)
+
+    def records(self):
+        """Flat list of (stream, call, Packet) in (stream, call, reference order)."""
         out = []
-        for i in range(n.value):
-            r = self._recs[i]
-            data = np.frombuffer(bytes(r.data[: r.nbytes]), dtype=np.uint8)
-            out.append((int(r.stream), int(r.call), Packet(int(r.index), data, float(r.rssi), float(r.snr))))
+        for r in self.results():
+            data = np.frombuffer(r["data"][: int(r["nbytes"])].tobytes(), dtype=np.uint8)  # read-only copy
+            out.append((int(r["stream"]), int(r["call"]),
+                        Packet(int(r["index"]), data, float(r["rssi"]), float(r["snr"]))))
         return out
 
     def packets(self) -> List[List[List[Packet]]]:

@@ -13,8 +13,20 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
 #include "rd_internal.h"
 #include "rd_math.h"
+
+// RD_DEBUG_HOST=1: print host-side phase times of rd_batch_results to stderr (diagnostic)
+static bool dbg_host() {
+    static int v = -1;
+    if (v < 0) v = getenv("RD_DEBUG_HOST") ? 1 : 0;
+    return v == 1;
+}
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ------------------------------------------------------------------------------------------
 // errors / device context
@@ -72,6 +84,25 @@ extern "C" int rd_set_device(int device) {
     return RD_OK;
 }
 
+// Wait for a stream by polling.  The runtime's blocking waits (hipStreamSynchronize, synchronous
+// hipMemcpy) were measured to add 10-20 ms of wake-up latency per call on this platform, an
+// order of magnitude more than a whole batch takes on the GPU.
+static int wait_stream(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return RD_OK;
+        if (e != hipErrorNotReady) return fail(RD_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+        __builtin_ia32_pause();
+    }
+}
+
+// device -> host copy of n bytes on `st`, completed on return (polling wait)
+static int copy_d2h(void *dst, const void *src, size_t n, hipStream_t st) {
+    if (n == 0) return RD_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st));
+    return wait_stream(st);
+}
+
 // ------------------------------------------------------------------------------------------
 // configuration (py:101-125)
 // ------------------------------------------------------------------------------------------
@@ -104,23 +135,50 @@ static int make_devcfg(const rd_config *c, rd_devcfg *d) {
 
 // Reference order inside one call: search is phase-major then ascending (py:175-186),
 // slice keeps the first occurrence of each byte string (py:203-205).
+// Records are ordered by (stream, call, index % S, index): small lists with std::sort, large
+// ones with stable LSD counting passes over an index array (a comparison sort that moves
+// 64-byte records costs tens of milliseconds at 2e4 packets).
 static void order_and_dedupe(std::vector<rd_packet> &recs, int S) {
-    std::sort(recs.begin(), recs.end(), [S](const rd_packet &a, const rd_packet &b) {
-        if (a.stream != b.stream) return a.stream < b.stream;
-        if (a.call != b.call) return a.call < b.call;
-        const int pa = a.index % S, pb = b.index % S;
-        if (pa != pb) return pa < pb;
-        return a.index < b.index;
-    });
+    const size_t n = recs.size();
+    if (n == 0) return;
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+    if (n < 256) {
+        std::sort(idx.begin(), idx.end(), [&](uint32_t ia, uint32_t ib) {
+            const rd_packet &a = recs[ia], &b = recs[ib];
+            if (a.stream != b.stream) return a.stream < b.stream;
+            if (a.call != b.call) return a.call < b.call;
+            const int pa = a.index % S, pb = b.index % S;
+            if (pa != pb) return pa < pb;
+            return a.index < b.index;
+        });
+    } else {
+        std::vector<uint32_t> tmp(n), count;
+        auto pass = [&](auto digit) {  // one stable counting pass on a 16-bit digit
+            count.assign((1u << 16) + 1, 0);
+            for (size_t i = 0; i < n; i++) count[digit(recs[idx[i]]) + 1]++;
+            for (uint32_t d = 0; d < (1u << 16); d++) count[d + 1] += count[d];
+            for (size_t i = 0; i < n; i++) tmp[count[digit(recs[idx[i]])]++] = idx[i];
+            idx.swap(tmp);
+        };
+        auto by_field = [&](auto field) {  // non-negative 32-bit field, low digit first
+            pass([&](const rd_packet &r) { return (uint32_t)field(r) & 0xFFFFu; });
+            pass([&](const rd_packet &r) { return (uint32_t)field(r) >> 16; });
+        };
+        by_field([](const rd_packet &r) { return r.index; });
+        pass([S](const rd_packet &r) { return (uint32_t)(r.index % S) & 0xFFFFu; });
+        by_field([](const rd_packet &r) { return r.call; });
+        by_field([](const rd_packet &r) { return r.stream; });
+    }
     std::vector<rd_packet> out;
-    out.reserve(recs.size());
+    out.reserve(n);
     size_t group = 0;
-    for (size_t i = 0; i < recs.size(); i++) {
-        if (i == 0 || recs[i].stream != recs[i - 1].stream || recs[i].call != recs[i - 1].call) group = out.size();
+    for (size_t i = 0; i < n; i++) {
+        const rd_packet &r = recs[idx[i]];
+        if (out.empty() || r.stream != out.back().stream || r.call != out.back().call) group = out.size();
         bool dup = false;
-        for (size_t k = group; k < out.size() && !dup; k++)
-            dup = memcmp(out[k].data, recs[i].data, (size_t)recs[i].nbytes) == 0;
-        if (!dup) out.push_back(recs[i]);
+        for (size_t k = group; k < out.size() && !dup; k++) dup = memcmp(out[k].data, r.data, (size_t)r.nbytes) == 0;
+        if (!dup) out.push_back(r);
     }
     recs.swap(out);
 }
@@ -142,8 +200,14 @@ struct rd_batch {
     rd_packet *d_recs = nullptr;
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {};
+    std::vector<hipEvent_t> evs;  // 5 events per timed run, read back in rd_batch_get_timing
+    size_t ev_runs = 0;           // timed runs recorded since the last rd_batch_get_timing
+    hipEvent_t *ev = nullptr;     // the current run's five events
     uint32_t h_cnt[RD_CNT_SLOTS] = {};
+    uint32_t *h_cnt_pin = nullptr;   // pinned: counters of the run in flight
+    rd_packet *h_recs_pin = nullptr; // pinned: records of the run in flight (rec_cap entries)
+    uint32_t rec_pin_cap = 0;
+    uint32_t spec_recs = 1024;       // records copied back speculatively with the counters
     uint64_t last_fix = 0, last_match = 0;
     rd_timing last_timing = {};
 };
@@ -169,7 +233,8 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
     if (n_streams < 1 || n_blocks < 1) return fail(RD_ERR_ARG, "n_streams and n_blocks must be >= 1");
     const long n = (long)n_blocks * cfg->block_size;
     const uint64_t runs = (uint64_t)n_streams * ((n + RD_RUN - 1) / RD_RUN);
-    if (n > 0x7FFFFFF0L || runs > 0xFFFFFFFFull) return fail(RD_ERR_ARG, "batch too large for 32-bit run ids");
+    if (n > 0x7FFFFFF0L || runs > 0x3FFFFFFFull)
+        return fail(RD_ERR_ARG, "batch too large: the packed-bit array must stay below 4 GiB per batch");
     rd_batch *b = new rd_batch();
     b->cfg = *cfg;
     b->dc = dc;
@@ -188,7 +253,8 @@ static int batch_alloc(rd_batch *b) {
     if (rc) return rc;
     const uint64_t runs = (uint64_t)b->n_streams * b->bits_stride;
     b->iq_bytes = (size_t)b->n_streams * b->n_samples * 2;
-    b->fix_cap = (uint32_t)std::min<uint64_t>(runs, std::max<uint64_t>(4096, runs / 8));
+    // guard-band list entries are 8-sample groups (4 per run); ~0.5 % of them on noise
+    b->fix_cap = (uint32_t)std::min<uint64_t>(4 * runs, std::max<uint64_t>(4096, runs / 4));
     b->match_cap = (uint32_t)std::min<uint64_t>((uint64_t)b->n_streams * (16 + 4ull * b->n_blocks), 1u << 26);
     b->rec_cap = 2 * b->match_cap;
     HIPCHK(hipMalloc(&b->d_iq, b->iq_bytes + RD_INPUT_PAD));
@@ -198,7 +264,9 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMalloc(&b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
-    for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc((void **)&b->h_cnt_pin, RD_CNT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
+    b->rec_pin_cap = b->rec_cap;
     b->dev_ready = true;
     return RD_OK;
 }
@@ -208,7 +276,8 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
     if (b->dev_ready && g_hip_pid == getpid()) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs);
-        for (auto &e : b->ev) if (e) hipEventDestroy(e);
+        hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
+        for (auto &e : b->evs) if (e) hipEventDestroy(e);
     }
     delete b;
 }
@@ -243,6 +312,11 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
                     b->d_recs, b->rec_cap, b->d_cnt, st);
     if (b->timing) hipEventRecord(b->ev[4], st);
+    // results come back with the run: counters plus as many records as the last run produced
+    // (+25 %); rd_batch_results fetches the remainder if this run produced more.
+    hipMemcpyAsync(b->h_cnt_pin, b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    const uint32_t spec = std::min(b->rec_cap, b->spec_recs);
+    if (spec) hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st);
 }
 
 extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
@@ -253,6 +327,15 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     b->stream = st;
     const rd_layout lay = batch_layout(b);
     HIPCHK(hipMemsetAsync(b->d_cnt, 0, RD_CNT_SLOTS * sizeof(uint32_t), st));
+    if (b->timing) {
+        if (b->evs.size() < 5 * (b->ev_runs + 1)) {
+            const size_t old = b->evs.size();
+            b->evs.resize(old + 5, nullptr);
+            for (size_t i = old; i < b->evs.size(); i++) HIPCHK(hipEventCreate(&b->evs[i]));
+        }
+        b->ev = &b->evs[5 * b->ev_runs];
+        b->ev_runs++;
+    }
     if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
     if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, b->d_cnt, st);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
@@ -269,8 +352,11 @@ static int batch_finish(rd_batch *b) {
     if (!b->ran) return fail(RD_ERR_STATE, "rd_batch_run has not been called");
     hipStream_t st = b->stream;
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipMemcpy(b->h_cnt, b->d_cnt, sizeof b->h_cnt, hipMemcpyDeviceToHost));
+        const double ta = now_ms();
+        int wrc = wait_stream(st);
+        if (wrc) return wrc;
+        memcpy(b->h_cnt, b->h_cnt_pin, sizeof b->h_cnt);
+        if (dbg_host()) fprintf(stderr, "[rd] finish: wait %.3f ms\n", now_ms() - ta);
         bool redo_search = false;
         if (b->fast_ok && b->h_cnt[RD_CNT_FIX] > b->fix_cap) {
             // guard list overflowed (degenerate input): re-evaluate every run exactly
@@ -278,29 +364,23 @@ static int batch_finish(rd_batch *b) {
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, 1, st);
             uint32_t cap = b->fix_cap;  // mark handled
             HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
-            b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
+            b->last_fix = (uint64_t)b->n_streams * b->bits_stride * 4;
             redo_search = true;
         } else if (attempt == 0) {
             b->last_fix = b->h_cnt[RD_CNT_FIX];
         }
         if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
-            hipFree(b->d_matches); hipFree(b->d_recs);
+            hipFree(b->d_matches); hipFree(b->d_recs); hipHostFree(b->h_recs_pin);
             b->match_cap = b->h_cnt[RD_CNT_MATCH] + 1024;
             b->rec_cap = 2 * b->match_cap;
             HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
             HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+            HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
+            b->rec_pin_cap = b->rec_cap;
             redo_search = true;
         }
         if (!redo_search) {
             b->last_match = b->h_cnt[RD_CNT_MATCH];
-            if (b->timing) {
-                rd_timing &t = b->last_timing;
-                hipEventElapsedTime(&t.demod_ms, b->ev[0], b->ev[1]);
-                hipEventElapsedTime(&t.fixup_ms, b->ev[1], b->ev[2]);
-                hipEventElapsedTime(&t.search_ms, b->ev[2], b->ev[3]);
-                hipEventElapsedTime(&t.slice_ms, b->ev[3], b->ev[4]);
-                hipEventElapsedTime(&t.total_ms, b->ev[0], b->ev[4]);
-            }
             return RD_OK;
         }
         const uint32_t zero[2] = {0, 0};
@@ -312,12 +392,23 @@ static int batch_finish(rd_batch *b) {
 
 extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     if (!b || !n) return fail(RD_ERR_ARG, "null argument");
+    const double t0 = now_ms();
     int rc = batch_finish(b);
     if (rc) return rc;
+    const double t1 = now_ms();
     const uint32_t nrec = std::min(b->h_cnt[RD_CNT_REC], b->rec_cap);
-    std::vector<rd_packet> recs(nrec);
-    if (nrec) HIPCHK(hipMemcpy(recs.data(), b->d_recs, (size_t)nrec * sizeof(rd_packet), hipMemcpyDeviceToHost));
+    const uint32_t have = std::min(b->rec_cap, b->spec_recs);
+    if (nrec > have) {  // more records than were copied back with the run: fetch the rest
+        rc = copy_d2h(b->h_recs_pin + have, b->d_recs + have, (size_t)(nrec - have) * sizeof(rd_packet), b->stream);
+        if (rc) return rc;
+    }
+    b->spec_recs = std::max<uint32_t>(1024, nrec + nrec / 4);
+    std::vector<rd_packet> recs(b->h_recs_pin, b->h_recs_pin + nrec);
+    const double t2 = now_ms();
     order_and_dedupe(recs, b->dc.S);
+    if (dbg_host())
+        fprintf(stderr, "[rd] results: finish %.3f ms, D2H %u recs %.3f ms, order+dedupe %.3f ms\n", t1 - t0, nrec,
+                t2 - t1, now_ms() - t2);
     *n = (int)recs.size();
     if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
     if (!recs.empty()) {
@@ -334,8 +425,7 @@ extern "C" int rd_batch_copy_bits(rd_batch *b, int stream, uint8_t *out, size_t 
     if (nbytes < need) return fail(RD_ERR_ARG, "bit buffer too small: %zu < %zu", nbytes, need);
     int rc = batch_finish(b);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(out, (const uint8_t *)(b->d_bits + (size_t)stream * b->bits_stride), need, hipMemcpyDeviceToHost));
-    return RD_OK;
+    return copy_d2h(out, (const uint8_t *)(b->d_bits + (size_t)stream * b->bits_stride), need, b->stream);
 }
 
 extern "C" int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out, size_t n) {
@@ -348,16 +438,15 @@ extern "C" int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, d
     double *d = nullptr;
     HIPCHK(hipMalloc(&d, n * sizeof(double)));
     rd_launch_disc(batch_layout(b), stream, (long)t0, (long)n, d, b->stream);
-    hipError_t e = hipMemcpyAsync(out, d, n * sizeof(double), hipMemcpyDeviceToHost, b->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    rc = copy_d2h(out, d, n * sizeof(double), b->stream);
     hipFree(d);
-    if (e != hipSuccess) return fail(RD_ERR_DEVICE, "copy_discriminated: %s", hipGetErrorString(e));
-    return RD_OK;
+    return rc;
 }
 
 extern "C" int rd_batch_set_timing(rd_batch *b, int enabled) {
     if (!b) return fail(RD_ERR_ARG, "null batch");
     b->timing = enabled != 0;
+    b->ev_runs = 0;
     return RD_OK;
 }
 
@@ -366,7 +455,27 @@ extern "C" int rd_batch_get_timing(rd_batch *b, rd_timing *out) {
     if (!b->timing) return fail(RD_ERR_STATE, "timing not enabled");
     int rc = batch_finish(b);
     if (rc) return rc;
-    *out = b->last_timing;
+    // mean over the runs recorded since the last call (events are only read here, after the
+    // timed region: hipEventElapsedTime costs milliseconds on ROCm 7.2)
+    rd_timing t = {};
+    for (size_t r = 0; r < b->ev_runs; r++) {
+        hipEvent_t *e = &b->evs[5 * r];
+        float v[5];
+        HIPCHK(hipEventElapsedTime(&v[0], e[0], e[1]));
+        HIPCHK(hipEventElapsedTime(&v[1], e[1], e[2]));
+        HIPCHK(hipEventElapsedTime(&v[2], e[2], e[3]));
+        HIPCHK(hipEventElapsedTime(&v[3], e[3], e[4]));
+        HIPCHK(hipEventElapsedTime(&v[4], e[0], e[4]));
+        t.demod_ms += v[0]; t.fixup_ms += v[1]; t.search_ms += v[2]; t.slice_ms += v[3]; t.total_ms += v[4];
+    }
+    if (b->ev_runs) {
+        const float k = 1.0f / (float)b->ev_runs;
+        t.demod_ms *= k; t.fixup_ms *= k; t.search_ms *= k; t.slice_ms *= k; t.total_ms *= k;
+    }
+    t.runs = (int32_t)b->ev_runs;
+    b->ev_runs = 0;
+    b->last_timing = t;
+    *out = t;
     return RD_OK;
 }
 
@@ -397,6 +506,9 @@ struct rd_demod {
     rd_match *d_matches = nullptr;
     rd_packet *d_recs = nullptr;
     double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
+    uint8_t *h_in = nullptr;        // pinned staging of one input block
+    uint32_t *h_cnt = nullptr;      // pinned
+    rd_packet *h_recs = nullptr;    // pinned, rec_cap entries
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     bool fast_ok = false;
 };
@@ -425,7 +537,7 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_ring, ring_bytes));
     HIPCHK(hipMemset(h->d_ring, 127, ring_bytes));
     HIPCHK(hipMalloc(&h->d_stage, 2 * B));
-    h->fix_cap = (uint32_t)((B + 31) / 32);
+    h->fix_cap = (uint32_t)(4 * ((B + 31) / 32));  // every 8-sample group of a block
     h->match_cap = (uint32_t)(B + 1);
     h->rec_cap = (uint32_t)(B + 1);
     HIPCHK(hipMalloc(&h->d_blockbits, ((B + 31) / 32) * 4));
@@ -438,6 +550,9 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(rd_packet)));
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&h->h_in, 16 * B, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     h->dev_ready = true;
     return RD_OK;
 }
@@ -448,6 +563,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_stage); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_recs); hipFree(h->d_tmp);
+        hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs);
     }
     delete h;
 }
@@ -525,7 +641,8 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
             HIPCHK(hipMemcpyAsync(r, r + 32 + 2 * B - 32, 32, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpyAsync(r + 32, r + 32 + 2 * B, 2 * B, hipMemcpyDeviceToDevice, st));
         }
-        HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, samples, 2 * B, hipMemcpyHostToDevice, st));
+        memcpy(h->h_in, samples, 2 * B);
+        HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, h->h_in, 2 * B, hipMemcpyHostToDevice, st));
     } else {
         double *r = h->d_cring;
         if (seen_before > 0) {
@@ -533,9 +650,11 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
             HIPCHK(hipMemcpyAsync(r + 32, r + 32 + 2 * B, 2 * B * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         if (is_complex) {
-            HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, samples, 2 * B * sizeof(double), hipMemcpyHostToDevice, st));
+            memcpy(h->h_in, samples, 2 * B * sizeof(double));
+            HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, h->h_in, 2 * B * sizeof(double), hipMemcpyHostToDevice, st));
         } else {
-            HIPCHK(hipMemcpyAsync(h->d_stage, samples, 2 * B, hipMemcpyHostToDevice, st));
+            memcpy(h->h_in, samples, 2 * B);
+            HIPCHK(hipMemcpyAsync(h->d_stage, h->h_in, 2 * B, hipMemcpyHostToDevice, st));
             rd_launch_lut(h->d_stage, r + 32 + 2 * B, B, st);
         }
     }
@@ -560,13 +679,19 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
         rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
                              (int)seen_before, h->d_recs, h->rec_cap, h->d_cnt, st);
     HIPCHK(hipGetLastError());
-    uint32_t cnt[RD_CNT_SLOTS];
-    HIPCHK(hipMemcpyAsync(cnt, h->d_cnt, sizeof cnt, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // counters and the first records come back with the block; polling wait (see wait_stream)
+    const uint32_t spec = std::min<uint32_t>(h->rec_cap, 32);
+    HIPCHK(hipMemcpyAsync(h->h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
+    rc = wait_stream(st);
+    if (rc) return rc;
     h->seen = seen_before + 1;
-    const uint32_t nrec = std::min(cnt[RD_CNT_REC], h->rec_cap);
-    std::vector<rd_packet> recs(nrec);
-    if (nrec) HIPCHK(hipMemcpy(recs.data(), h->d_recs, (size_t)nrec * sizeof(rd_packet), hipMemcpyDeviceToHost));
+    const uint32_t nrec = std::min(h->h_cnt[RD_CNT_REC], h->rec_cap);
+    if (nrec > spec) {
+        rc = copy_d2h(h->h_recs + spec, h->d_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
+        if (rc) return rc;
+    }
+    std::vector<rd_packet> recs(h->h_recs, h->h_recs + nrec);
     order_and_dedupe(recs, h->dc.S);
     *n = (int)recs.size();
     if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
@@ -589,8 +714,7 @@ extern "C" int rd_copy_discriminated(rd_demod *h, double *out, size_t n) {
     if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), 0, -(long)B, 2 * (long)B, h->d_tmp, nullptr);
     else rd_launch_cplx_disc(demod_clayout(h, h->seen - 1), -(long)B, 2 * (long)B, h->d_tmp, nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(out, h->d_tmp, n * sizeof(double), hipMemcpyDeviceToHost));
-    return RD_OK;
+    return copy_d2h(out, h->d_tmp, n * sizeof(double), nullptr);
 }
 
 extern "C" int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_complex) {
@@ -605,8 +729,7 @@ extern "C" int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_c
     if (!h->cplx_mode) rd_launch_filtered(demod_layout(h, h->seen - 1), 0, -1, (long)B + 1, h->d_tmp, nullptr);
     else rd_launch_cplx_filtered(demod_clayout(h, h->seen - 1), -1, (long)B + 1, h->d_tmp, nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(out_interleaved, h->d_tmp, 2 * n_complex * sizeof(double), hipMemcpyDeviceToHost));
-    return RD_OK;
+    return copy_d2h(out_interleaved, h->d_tmp, 2 * n_complex * sizeof(double), nullptr);
 }
 
 extern "C" int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n) {
@@ -618,7 +741,8 @@ extern "C" int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n) {
         return RD_OK;
     }
     std::vector<uint32_t> words((L + 31) / 32);
-    HIPCHK(hipMemcpy(words.data(), h->d_win[h->cur_win], words.size() * 4, hipMemcpyDeviceToHost));
+    int rc = copy_d2h(words.data(), h->d_win[h->cur_win], words.size() * 4, nullptr);
+    if (rc) return rc;
     for (size_t t = 0; t < L; t++) out[t] = (uint8_t)((words[t >> 5] >> (t & 31)) & 1u);  // unpack only
     return RD_OK;
 }

@@ -14,12 +14,15 @@
 // HBM-bound scan: no MFMA (there is no dense contraction).  The input is read once with
 // 16-byte coalesced global->LDS loads; each lane then owns 32 consecutive samples so the
 // 9-tap window lives in registers and one lane emits one packed 32-bit word.
+#include <cstdlib>
+
 #include "rd_internal.h"
 #include "rd_math.h"
 
 #define RD_WG 256
 #define RD_WAVES (RD_WG / 64)
 #define RD_LDS_WAVE (32 + RD_TILE_BYTES)  // 32 B halo + one 4 KiB tile, private to a wave
+#define RD_PEND 128                       // guard-band run ids staged per wave before one atomic
 
 // Window bytes of one lane held in six dwordx4 registers: byte i of the window
 // (sample t0-10 is byte 0) is byte 12+i of the 96-byte chunk starting 32 B before the run.
@@ -33,73 +36,135 @@ struct rd_reg_src {
         const uint32_t d = q[b >> 2];
         float r;
         switch (b & 3) {
-            case 0: asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(d)); break;
-            case 1: asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(d)); break;
-            case 2: asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(d)); break;
-            default: asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(d)); break;
+            case 0: asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(d)); break;
+            case 1: asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(d)); break;
+            case 2: asm volatile("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(d)); break;
+            default: asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(d)); break;
         }
         return r;
     }
 };
 
+// Append a wave's staged ids to the global list with one atomic (count is wave-uniform).
+__device__ __forceinline__ void rd_flush_pending(const uint32_t *pend, uint32_t count, uint32_t *fix_list,
+                                                 uint32_t fix_cap, uint32_t *counters, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staged ids written by other lanes
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[RD_CNT_FIX], count);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t i = lane; i < count; i += 64)
+        if (base + i < fix_cap) fix_list[base + i] = pend[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // k_demod_bits: one wave = one 2048-sample tile per iteration, grid-stride over tiles.
 // LDS is wave-private (no workgroup barrier anywhere): [halo 32 B][tile 4096 B].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RD_WG) void k_demod_bits(rd_layout lay, uint32_t tiles_per_stream,
+// LDS image of a tile (wave-private).  One global_load_lds_dwordx4 writes 64 consecutive
+// 16-byte slots (slot = lane), so the *source* chunk of each lane is permuted instead
+// (cdna_hip_programming.md rule 21): slot 64j + l holds chunk 64j + 4(l%16) + l/16 of the
+// tile.  Lane L then finds its four chunks 4L..4L+3 at slots 64(L/16) + 16i + L%16 - for a
+// fixed i, 16 neighbouring lanes read 16 neighbouring slots: ds_read_b128 without bank
+// conflicts (a plain linear image would be a 4-way conflict at the 64-byte lane stride).
+__device__ __forceinline__ void rd_issue_tile_loads(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *my,
+                                                    int lane) {
+    const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
+    const int perm = 4 * (lane & 15) + (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024 + perm * 16),
+                                         (__attribute__((address_space(3))) void *)(my + 32 + j * 1024), 16, 0, 0);
+    // halo: the 32 bytes before the tile (previous tile, or the caller's history bytes).
+    // With zero history there is nothing to read: run 0 is always re-evaluated exactly.
+    const bool has_halo = (ti > 0) || lay.hist_mode;
+    if (lane < 2)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(src + (has_halo ? -32 : 0) + lane * 16),
+            (__attribute__((address_space(3))) void *)(my), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t tiles_per_stream,
                                                       uint32_t runs_per_stream, uint32_t *fix_list,
                                                       uint32_t fix_cap, uint32_t *counters) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[RD_WAVES][RD_LDS_WAVE];
+    // Guard-band run ids are staged per wave and appended to the global list RD_PEND at a
+    // time: one returning atomic per ~100 ids instead of one per tile (a single counter
+    // word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue").
+    __shared__ uint32_t pend[RD_WAVES][RD_PEND];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile bookkeeping stays on the SALU
     uint8_t *my = lds[wave];
-    const uint64_t total = (uint64_t)lay.n_streams * tiles_per_stream;
-    const uint64_t nwaves = (uint64_t)gridDim.x * RD_WAVES;
-    for (uint64_t tile = (uint64_t)blockIdx.x * RD_WAVES + wave; tile < total; tile += nwaves) {
-        const uint32_t s = (uint32_t)(tile / tiles_per_stream);
-        const uint32_t ti = (uint32_t)(tile - (uint64_t)s * tiles_per_stream);
-        const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
-        // global -> LDS, 16 B per lane, 1 KiB contiguous per instruction (LDS address is
-        // wave-uniform base + lane*16).  Reads past the stream end land in the next stream
-        // or the RD_INPUT_PAD tail; those samples are never turned into output.
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void *)(my + 32 + j * 1024), 16, 0, 0);
-        // halo: the 32 bytes before the tile (previous tile, or the caller's history bytes).
-        // With zero history there is nothing to read: run 0 is always re-evaluated exactly.
-        const bool has_halo = (ti > 0) || lay.hist_mode;
-        if (lane < 2)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + (has_halo ? -32 : 0) + lane * 16),
-                (__attribute__((address_space(3))) void *)(my), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t *mypend = pend[wave];
+    uint32_t npend = 0;  // wave-uniform
+    const uint32_t nwaves = gridDim.x * RD_WAVES;
+    // tile = s * tiles_per_stream + ti advances by nwaves per iteration: (s, ti) += (dq, dr) with carry
+    const uint32_t dq = nwaves / tiles_per_stream, dr = nwaves % tiles_per_stream;
+    // per-lane LDS addresses: own chunks i = 0..3 at own + 256 i; the previous lane's chunks
+    // 2, 3 (this lane's halo) at prev + 512, prev + 768; lane 0 takes the halo region.
+    const uint8_t *own = my + 32 + 16 * (64 * (lane >> 4) + (lane & 15));
+    const int pl = lane - 1;
+    const uint8_t *h0 = lane ? my + 32 + 16 * (64 * (pl >> 4) + 32 + (pl & 15)) : my;
+    const uint8_t *h1 = lane ? h0 + 256 : my + 16;
 
+    const uint32_t first = blockIdx.x * RD_WAVES + wave;
+    uint32_t s = first / tiles_per_stream, ti = first % tiles_per_stream;
+    if (s < (uint32_t)lay.n_streams) rd_issue_tile_loads(lay, s, ti, my, lane);
+    while (s < (uint32_t)lay.n_streams) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile has landed in LDS
         rd_reg_src win;
-        const uint4 *chunk = (const uint4 *)(my + 64 * lane);
+        {
+            const uint4 a = *(const uint4 *)h0, b = *(const uint4 *)h1;
+            win.q[0] = a.x; win.q[1] = a.y; win.q[2] = a.z; win.q[3] = a.w;
+            win.q[4] = b.x; win.q[5] = b.y; win.q[6] = b.z; win.q[7] = b.w;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const uint4 v = chunk[j];
-            win.q[4 * j + 0] = v.x; win.q[4 * j + 1] = v.y; win.q[4 * j + 2] = v.z; win.q[4 * j + 3] = v.w;
+            for (int i = 0; i < 4; i++) {
+                const uint4 v = *(const uint4 *)(own + 256 * i);
+                win.q[8 + 4 * i] = v.x; win.q[9 + 4 * i] = v.y; win.q[10 + 4 * i] = v.z; win.q[11 + 4 * i] = v.w;
+            }
         }
+        // The window is in registers: the same LDS buffer can take the next tile while this
+        // one is computed (~2000 VALU instructions cover the HBM latency).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t ns = s + dq, nti = ti + dr;
+        if (nti >= tiles_per_stream) { nti -= tiles_per_stream; ns++; }
+        if (ns < (uint32_t)lay.n_streams) rd_issue_tile_loads(lay, ns, nti, my, lane);
+
         const rd_run_result r = rd_fast_run(win);
 
         const uint32_t run = ti * 64 + lane;
         const uint32_t t0 = run * RD_RUN;
+        uint32_t gmask = 0;  // groups of 8 samples inside the guard band
         if (t0 < lay.n_samples) {
             uint32_t word = r.word;
             const uint32_t left = lay.n_samples - t0;
             if (left < RD_RUN) word &= (1u << left) - 1u;
             lay.bits[(size_t)s * lay.bits_stride + run] = word;
-            const bool flag = !(r.nmin > rd_run_threshold(r.fmax)) || (run == 0 && !lay.hist_mode);
-            if (flag) {
-                const uint32_t idx = atomicAdd(&counters[RD_CNT_FIX], 1u);
-                if (idx < fix_cap) fix_list[idx] = s * runs_per_stream + run;
+            gmask = (run == 0 && !lay.hist_mode) ? 0xFu : rd_guard_mask(r);
+            if (left < RD_RUN) gmask &= (1u << ((left + RD_GROUP - 1) / RD_GROUP)) - 1u;
+        }
+        if (__ballot(gmask != 0)) {  // wave-uniform, ~60 % of the tiles on noise
+            // list entry = byte offset of the group's output byte in the bits array
+            const uint32_t byte0 = (uint32_t)(((size_t)s * lay.bits_stride + run) * 4);
+#pragma unroll
+            for (int g = 0; g < RD_GROUPS; g++) {
+                const bool flag = (gmask >> g) & 1;
+                const uint64_t fm = __ballot(flag);
+                if (!fm) continue;
+                const uint32_t nf = (uint32_t)__popcll(fm);
+                if (npend + nf > RD_PEND) {
+                    rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
+                    npend = 0;
+                }
+                if (flag)
+                    mypend[npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0))] = byte0 + g;
+                npend += nf;
             }
         }
-        // the next iteration's LDS-DMA must not overtake this iteration's ds_reads
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        s = ns;
+        ti = nti;
     }
+    if (npend) rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
 }
 
 void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st) {
@@ -107,7 +172,14 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
     const uint64_t total = (uint64_t)lay.n_streams * tps;
     uint64_t wgs = (total + RD_WAVES - 1) / RD_WAVES;
-    const uint64_t max_wgs = 256ull * 8;  // 8 workgroups of 4 waves per CU: 32 waves/CU
+    // persistent grid: workgroups per CU (72 VGPRs and 18.5 KiB LDS admit 7); RD_K1_WGS_PER_CU overrides
+    static int per_cu = 0;
+    if (!per_cu) {
+        const char *e = getenv("RD_K1_WGS_PER_CU");
+        per_cu = e ? atoi(e) : 7;
+        if (per_cu < 1 || per_cu > 8) per_cu = 7;
+    }
+    const uint64_t max_wgs = 256ull * per_cu;
     if (wgs > max_wgs) wgs = max_wgs;
     if (wgs == 0) return;
     hipLaunchKernelGGL(k_demod_bits, dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps, fix_list, fix_cap,
@@ -128,16 +200,25 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
     }
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const uint64_t id = all ? i : fix_list[i];
-        const uint32_t s = (uint32_t)(id / runs_per_stream);
-        const uint32_t run = (uint32_t)(id - (uint64_t)s * runs_per_stream);
-        const long t0 = (long)run * RD_RUN;
         rd_stream_view v;
-        v.base = lay.iq + (size_t)s * lay.stream_stride;
         v.valid_from = lay.valid_from;
         v.n = lay.n_samples;
-        const long left = (long)lay.n_samples - t0;
-        lay.bits[(size_t)s * lay.bits_stride + run] = rd_exact_run(v, t0, left < RD_RUN ? (int)left : RD_RUN);
+        if (all) {  // every run, one output word each
+            const uint32_t s = (uint32_t)(i / runs_per_stream);
+            const uint32_t run = (uint32_t)(i - (uint64_t)s * runs_per_stream);
+            const long t0 = (long)run * RD_RUN;
+            v.base = lay.iq + (size_t)s * lay.stream_stride;
+            const long left = (long)lay.n_samples - t0;
+            lay.bits[(size_t)s * lay.bits_stride + run] = rd_exact_run(v, t0, left < RD_RUN ? (int)left : RD_RUN);
+        } else {  // listed groups of 8 samples, one output byte each
+            const uint32_t off = fix_list[i];
+            const uint32_t bytes_per_stream = (uint32_t)(lay.bits_stride * 4);
+            const uint32_t s = off / bytes_per_stream;
+            const long t0 = (long)(off - s * bytes_per_stream) * RD_GROUP;
+            v.base = lay.iq + (size_t)s * lay.stream_stride;
+            const long left = (long)lay.n_samples - t0;
+            ((uint8_t *)lay.bits)[off] = (uint8_t)rd_exact_run(v, t0, left < RD_GROUP ? (int)left : RD_GROUP);
+        }
     }
 }
 
@@ -153,8 +234,11 @@ void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fi
 }
 
 // ------------------------------------------------------------------------------------------
-// k_search: bit-parallel preamble match.  One thread = 32 consecutive positions.
-// match[p] = AND_m (bit[p + m*S] == preamble[m]).
+// k_search: bit-parallel preamble match (py:171-188, go:115-131).
+// match[p] = AND_k (bit[p + k*S] == preamble[k]).  One lane = 128 consecutive positions
+// (4 output words); the words that cover them are loaded once and every tap is a funnel
+// shift (v_alignbit_b32).  Persistent waves; matches are staged in LDS per wave and appended
+// to the global list ~100 at a time (a single counter word sustains only ~90 atomics/us).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rd_word_at(const uint32_t *w, long nwords, long i) {
     return (i >= 0 && i < nwords) ? w[i] : 0u;
@@ -169,35 +253,101 @@ __device__ __forceinline__ uint32_t rd_bits32_at(const uint32_t *w, long nwords,
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+#define RD_SEARCH_OUT 4     // output words (32 positions each) per lane
+#define RD_MATCH_PEND 128   // staged matches per wave
+
+__device__ __forceinline__ void rd_flush_matches(const rd_match *pend, uint32_t count, rd_match *matches,
+                                                 uint32_t match_cap, uint32_t *counters, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[RD_CNT_MATCH], count);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (uint32_t i = lane; i < count; i += 64)
+        if (base + i < match_cap) matches[base + i] = pend[i];
+}
+
+// S_ > 0: compile-time symbol length / preamble length (register funnel with constant
+// shifts); S_ == 0: run-time cfg.S / cfg.P (words fetched per tap).
+template <int S_, int P_>
 __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
                                                 long base, long groups_per_stream, long p_lo, long p_hi,
                                                 rd_devcfg cfg, rd_match *matches, uint32_t match_cap,
                                                 uint32_t *counters) {
-    const uint64_t total = (uint64_t)n_streams * groups_per_stream;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const uint32_t s = (uint32_t)(g / groups_per_stream);
-        const long gi = (long)(g - (uint64_t)s * groups_per_stream);
-        const long p0 = base + 32 * gi;
-        const uint32_t *w = bits + (size_t)s * bits_stride;
-        uint32_t m = 0xFFFFFFFFu;
-        for (int k = 0; k < cfg.P; k++) {
-            const uint32_t v = rd_bits32_at(w, nwords, p0 + (long)k * cfg.S);
-            m &= ((cfg.pre_mask >> k) & 1) ? v : ~v;
+    __shared__ rd_match pend_all[4][RD_MATCH_PEND];
+    const int lane = threadIdx.x & 63;
+    rd_match *pend = pend_all[threadIdx.x >> 6];
+    uint32_t npend = 0;  // wave-uniform
+    const uint64_t total = (uint64_t)n_streams * groups_per_stream;  // lane-groups of 128 positions
+    const uint64_t nwave_groups = (total + 63) / 64;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t wg = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wg < nwave_groups; wg += nwaves) {
+        const uint64_t g = wg * 64 + lane;
+        uint32_t m[RD_SEARCH_OUT] = {0, 0, 0, 0};
+        uint32_t s = 0;
+        long p0 = 0;
+        if (g < total) {
+            s = (uint32_t)(g / groups_per_stream);
+            const long gi = (long)(g - (uint64_t)s * groups_per_stream);
+            p0 = base + 32L * RD_SEARCH_OUT * gi;
+            const uint32_t *w = bits + (size_t)s * bits_stride;
+#pragma unroll
+            for (int o = 0; o < RD_SEARCH_OUT; o++) m[o] = 0xFFFFFFFFu;
+            if constexpr (S_ > 0) {
+                constexpr int NW = RD_SEARCH_OUT + ((P_ - 1) * S_ + 31) / 32 + 1;
+                const long w0 = p0 >> 5;
+                uint32_t r[NW];
+#pragma unroll
+                for (int j = 0; j < NW; j++) r[j] = rd_word_at(w, nwords, w0 + j);
+#pragma unroll
+                for (int k = 0; k < P_; k++) {
+                    const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
+                    const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
+#pragma unroll
+                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                        const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[o + wj + 1], r[o + wj], sh) : r[o + wj];
+                        m[o] &= v ^ x;
+                    }
+                }
+            } else {
+                for (int k = 0; k < cfg.P; k++) {
+                    const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int o = 0; o < RD_SEARCH_OUT; o++)
+                        m[o] &= rd_bits32_at(w, nwords, p0 + 32 * o + (long)k * cfg.S) ^ x;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < RD_SEARCH_OUT; o++) {  // keep positions inside [p_lo, p_hi]
+                const long q0 = p0 + 32 * o;
+                if (q0 < p_lo) m[o] &= (p_lo - q0 >= 32) ? 0u : (0xFFFFFFFFu << (p_lo - q0));
+                if (q0 + 31 > p_hi) m[o] &= (p_hi < q0) ? 0u : (0xFFFFFFFFu >> (31 - (p_hi - q0)));
+            }
         }
-        // keep positions inside [p_lo, p_hi]
-        if (p0 < p_lo) m &= (p_lo - p0 >= 32) ? 0u : (0xFFFFFFFFu << (p_lo - p0));
-        if (p0 + 31 > p_hi) m &= (p_hi < p0) ? 0u : (0xFFFFFFFFu >> (31 - (p_hi - p0)));
-        while (m) {
-            const int b = __builtin_ctz(m);
-            m &= m - 1;
-            const uint32_t idx = atomicAdd(&counters[RD_CNT_MATCH], 1u);
-            if (idx < match_cap) {
-                matches[idx].stream = (int32_t)s;
-                matches[idx].pos = (int32_t)(p0 + b);
+#pragma unroll
+        for (int o = 0; o < RD_SEARCH_OUT; o++) {
+            uint32_t mm = m[o];
+            uint64_t any = __ballot(mm != 0);
+            while (any) {  // each round, every lane with matches left contributes its lowest one
+                const uint32_t nf = (uint32_t)__popcll(any);
+                if (npend + nf > RD_MATCH_PEND) {
+                    rd_flush_matches(pend, npend, matches, match_cap, counters, lane);
+                    npend = 0;
+                }
+                if (mm) {
+                    const int bpos = __builtin_ctz(mm);
+                    mm &= mm - 1;
+                    rd_match e;
+                    e.stream = (int32_t)s;
+                    e.pos = (int32_t)(p0 + 32 * o + bpos);
+                    pend[npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0))] = e;
+                }
+                npend += nf;
+                any = __ballot(mm != 0);
             }
         }
     }
+    if (npend) rd_flush_matches(pend, npend, matches, match_cap, counters, lane);
 }
 
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
@@ -205,61 +355,110 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
                       hipStream_t st) {
     if (p_hi < p_lo || n_streams == 0) return;
     const long base = (p_lo >> 5) << 5;  // floor to a word boundary (p_lo may be negative)
-    const long groups = ((p_hi - base) >> 5) + 1;
     const long nwords = (n_bits + 31) / 32;
+    const long groups = (p_hi - base) / (32 * RD_SEARCH_OUT) + 1;
     const uint64_t total = (uint64_t)n_streams * groups;
     uint64_t wgs = (total + 255) / 256;
-    if (wgs > 256ull * 16) wgs = 256ull * 16;
-    hipLaunchKernelGGL(k_search, dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams, nwords, base,
-                       groups, p_lo, p_hi, cfg, matches, match_cap, counters);
+    if (wgs > 256ull * 8) wgs = 256ull * 8;
+    if (cfg.S == 14 && cfg.P == 16)  // the Davis configuration (protocol.py:68-76)
+        hipLaunchKernelGGL((k_search<14, 16>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams,
+                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
+    else
+        hipLaunchKernelGGL((k_search<0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams,
+                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_slice: one wave per match.  Packs packet_symbols bits at stride S (py:197-200) and
-// evaluates the reference's RSSI/SNR windows (py:207-236) in float64.
+// k_slice: one lane per match.  Decides which call(s) report it (py:194), reserves record
+// slots (one atomic per wave) and packs packet_symbols bits at stride S (py:197-200).
+// k_rssi: one wave per record, evaluates the reference's RSSI/SNR windows (py:207-236) in
+// float64 (<= 2*preamble_length fir9 outputs per record, 64 lanes in parallel).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rd_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return __shfl(v, 0, 64);
-}
-
 __device__ __forceinline__ uint32_t rd_bit_at(const uint32_t *w, long nwords, long o) {
     return (rd_word_at(w, nwords, o >> 5) >> (o & 31)) & 1u;
 }
 
-template <class View>
-__device__ __forceinline__ void rd_emit_record(const View &v, long f_origin, const uint32_t *w, long nwords, long pos,
+// All lanes of the wave must call this (valid = this lane has a record to emit).
+__device__ __forceinline__ void rd_emit_record(bool valid, const uint32_t *w, long nwords, long pos,
                                                const rd_devcfg &cfg, int stream, int call, long q, rd_packet *recs,
                                                uint32_t rec_cap, uint32_t *counters, int lane) {
-    // filtered[j] = f[f_origin + j - 1], j in [0, B]  (py:133,161: newest block only)
+    const uint64_t vm = __ballot(valid);
+    if (!vm) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[RD_CNT_REC], (uint32_t)__popcll(vm));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t slot =
+        base + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0));
+    if (!valid || slot >= rec_cap) return;
+    rd_packet *o = &recs[slot];
+    for (int bi = 0; bi < RD_MAX_PKT_BYTES; bi++) {
+        uint32_t byte = 0;
+        if (bi < cfg.nbytes)
+            for (int k = 0; k < 8; k++) {
+                const int i = bi * 8 + k;
+                if (i < cfg.K) byte = (byte << 1) | rd_bit_at(w, nwords, pos + (long)i * cfg.S);
+            }
+        o->data[bi] = (uint8_t)byte;
+    }
+    o->stream = stream; o->call = call; o->index = (int32_t)q; o->nbytes = cfg.nbytes;
+    o->rssi = 0.0; o->snr = 0.0;  // filled by k_rssi
+}
+
+__global__ __launch_bounds__(64) void k_slice(const uint32_t *bits, size_t bits_stride, long nwords, rd_devcfg cfg,
+                                              const rd_match *matches, uint32_t match_cap, int batch_mode,
+                                              int n_calls, int call, rd_packet *recs, uint32_t rec_cap,
+                                              uint32_t *counters) {
+    const int lane = threadIdx.x & 63;
+    uint32_t count = counters[RD_CNT_MATCH];
+    if (count > match_cap) count = match_cap;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (count + stride - 1) / stride;  // wave-uniform trip count
+    for (uint32_t rnd = 0; rnd < rounds; rnd++) {
+        const uint32_t i = rnd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool have = i < count;
+        rd_match mt = {0, 0};
+        if (have) mt = matches[i];
+        const uint32_t *w = bits + (size_t)mt.stream * bits_stride;
+        if (batch_mode) {
+            // call b reports absolute positions w_b <= p <= w_b + B, w_b = (b+1)B - L (py:194: q <= B)
+            const long pl = (long)mt.pos + cfg.L;
+            const long b_hi = pl / cfg.B - 1;  // floor: pl >= B because p >= B - L
+            const long b_lo = (pl % cfg.B == 0) ? b_hi - 1 : b_hi;
+            for (int j = 0; j < 2; j++) {
+                const long b = b_hi - j;
+                const bool ok = have && b >= b_lo && b >= 0 && b < n_calls;
+                const long q = (long)mt.pos - ((b + 1) * (long)cfg.B - cfg.L);
+                rd_emit_record(ok, w, nwords, mt.pos, cfg, mt.stream, (int)b, q, recs, rec_cap, counters, lane);
+            }
+        } else {
+            rd_emit_record(have, w, nwords, mt.pos, cfg, mt.stream, call, mt.pos, recs, rec_cap, counters, lane);
+        }
+    }
+}
+
+__device__ __forceinline__ double rd_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+
+// filtered[j] = f[origin + j - 1], j in [0, B] (py:133,161: newest block only); origin is
+// call*B in batch mode and 0 (the newest block's first sample) in streaming mode.
+template <class View>
+__device__ __forceinline__ void rd_rssi_record(const View &v, long origin, const rd_devcfg &cfg, rd_packet *o,
+                                               int lane) {
+    const long q = o->index;
     const long ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
     const long pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
     double noise = 0.0, sig = 0.0;
     for (long j = ns + lane; j < pe; j += 64) {
-        const rd_d2 f = rd_f_f64(v, f_origin + j - 1);
+        const rd_d2 f = rd_f_f64(v, origin + j - 1);
         const double p = f.x * f.x + f.y * f.y;
         if (j < q) noise += p; else sig += p;
     }
     noise = rd_wave_sum(noise);
     sig = rd_wave_sum(sig);
-    uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(&counters[RD_CNT_REC], 1u);
-    slot = __shfl(slot, 0, 64);
-    if (slot >= rec_cap) return;
-    rd_packet *o = &recs[slot];
-    if (lane < RD_MAX_PKT_BYTES) {
-        uint32_t byte = 0;
-        if (lane < cfg.nbytes) {
-            for (int k = 0; k < 8; k++) {
-                const int i = lane * 8 + k;
-                if (i < cfg.K) byte = (byte << 1) | rd_bit_at(w, nwords, pos + (long)i * cfg.S);
-            }
-        }
-        o->data[lane] = (uint8_t)byte;
-    }
     if (lane == 0) {
-        o->stream = stream; o->call = call; o->index = (int32_t)q; o->nbytes = cfg.nbytes;
         const double noise_power = (q > ns) ? noise / (double)(q - ns) : 1e-9;
         const double signal_power = (pe > q) ? sig / (double)(pe - q) : __builtin_nan("");
         o->rssi = signal_power > 0 ? 10.0 * log10(signal_power) : -120.0;
@@ -267,46 +466,48 @@ __device__ __forceinline__ void rd_emit_record(const View &v, long f_origin, con
     }
 }
 
-__global__ __launch_bounds__(256) void k_slice(rd_layout lay, const uint32_t *bits, size_t bits_stride, long nwords,
-                                               rd_devcfg cfg, const rd_match *matches, uint32_t match_cap,
-                                               int batch_mode, int n_calls, int call, rd_packet *recs,
-                                               uint32_t rec_cap, uint32_t *counters) {
+__global__ __launch_bounds__(256) void k_rssi(rd_layout lay, rd_devcfg cfg, int batch_mode, rd_packet *recs,
+                                              uint32_t rec_cap, const uint32_t *counters) {
     const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_MATCH];
-    if (count > match_cap) count = match_cap;
+    uint32_t count = counters[RD_CNT_REC];
+    if (count > rec_cap) count = rec_cap;
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
-        const rd_match mt = matches[i];
-        const uint32_t *w = bits + (size_t)mt.stream * bits_stride;
+        rd_packet *o = &recs[i];
         rd_stream_view v;
-        v.base = lay.iq + (size_t)mt.stream * lay.stream_stride;
+        v.base = lay.iq + (size_t)o->stream * lay.stream_stride;
         v.valid_from = lay.valid_from;
         v.n = lay.n_samples;
-        if (batch_mode) {
-            // call b reports absolute positions w_b <= p <= w_b + B, w_b = (b+1)B - L (py:194: q <= B)
-            const long pl = (long)mt.pos + cfg.L;
-            long b_hi = pl / cfg.B - 1;            // floor: pl >= B because p >= B - L
-            long b_lo = (pl % cfg.B == 0) ? b_hi - 1 : b_hi;
-            for (long b = b_lo; b <= b_hi; b++) {
-                if (b < 0 || b >= n_calls) continue;
-                const long q = (long)mt.pos - ((b + 1) * (long)cfg.B - cfg.L);
-                rd_emit_record(v, b * (long)cfg.B, w, nwords, mt.pos, cfg, mt.stream, (int)b, q, recs, rec_cap,
-                               counters, lane);
-            }
-        } else {
-            rd_emit_record(v, 0, w, nwords, mt.pos, cfg, mt.stream, call, mt.pos, recs, rec_cap, counters, lane);
-        }
+        rd_rssi_record(v, batch_mode ? (long)o->call * cfg.B : 0, cfg, o, lane);
     }
+}
+
+__global__ __launch_bounds__(256) void k_cplx_rssi(rd_cplx_view v, rd_devcfg cfg, rd_packet *recs, uint32_t rec_cap,
+                                                   const uint32_t *counters) {
+    const int lane = threadIdx.x & 63;
+    uint32_t count = counters[RD_CNT_REC];
+    if (count > rec_cap) count = rec_cap;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw)
+        rd_rssi_record(v, 0, cfg, &recs[i], lane);
+}
+
+static uint32_t rd_rssi_grid(uint32_t rec_cap) {
+    uint32_t wgs = (rec_cap + 3) / 4;
+    if (wgs > 4096) wgs = 4096;
+    return wgs ? wgs : 1;
 }
 
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
                      rd_packet *recs, uint32_t rec_cap, uint32_t *counters, hipStream_t st) {
-    uint32_t wgs = (match_cap + 3) / 4;
-    if (wgs > 2048) wgs = 2048;
+    uint32_t wgs = (match_cap + 63) / 64;  // 64-thread workgroups: one wave each, spread over the CUs
+    if (wgs > 4096) wgs = 4096;
     if (wgs == 0) wgs = 1;
-    hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(256), 0, st, lay, bits, bits_stride, (n_bits + 31) / 32, cfg, matches,
+    hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(64), 0, st, bits, bits_stride, (n_bits + 31) / 32, cfg, matches,
                        match_cap, batch_mode, n_calls, call, recs, rec_cap, counters);
+    hipLaunchKernelGGL(k_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, lay, cfg, batch_mode, recs, rec_cap,
+                       counters);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -416,28 +617,16 @@ void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double 
     hipLaunchKernelGGL(k_filt<rd_cplx_view>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, t0, n, out);
 }
 
-__global__ __launch_bounds__(256) void k_cplx_slice(rd_cplx_view v, const uint32_t *bits, long nwords, rd_devcfg cfg,
-                                                    const rd_match *matches, uint32_t match_cap, int call,
-                                                    rd_packet *recs, uint32_t rec_cap, uint32_t *counters) {
-    const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_MATCH];
-    if (count > match_cap) count = match_cap;
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
-        const rd_match mt = matches[i];
-        rd_emit_record(v, 0, bits, nwords, mt.pos, cfg, 0, call, mt.pos, recs, rec_cap, counters, lane);
-    }
-}
-
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
                           const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t rec_cap,
                           uint32_t *counters, hipStream_t st) {
-    uint32_t wgs = (match_cap + 3) / 4;
-    if (wgs > 2048) wgs = 2048;
+    uint32_t wgs = (match_cap + 63) / 64;
+    if (wgs > 4096) wgs = 4096;
     if (wgs == 0) wgs = 1;
     rd_cplx_view v = {lay.x, lay.valid_from, lay.n};
-    hipLaunchKernelGGL(k_cplx_slice, dim3(wgs), dim3(256), 0, st, v, bits, (n_bits + 31) / 32, cfg, matches,
-                       match_cap, call, recs, rec_cap, counters);
+    hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(64), 0, st, bits, (size_t)0, (n_bits + 31) / 32, cfg, matches,
+                       match_cap, 0, 0, call, recs, rec_cap, counters);
+    hipLaunchKernelGGL(k_cplx_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, v, cfg, recs, rec_cap, counters);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -28,6 +28,12 @@
 #define RD_HDM inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RD_SCHED_FENCE() do { } while (0)
+#endif
+
 #define RD_RUN 32          // samples per lane run (one packed output word)
 #define RD_HALO 10         // f[t0-1] needs y[t0-10 .. t0-2]
 #define RD_WIN (RD_RUN + 9) // samples a run reads: t0-10 .. t0+30
@@ -65,11 +71,17 @@ struct rd_f2 {
 };
 
 // Result of the fast evaluation of one run.
+#define RD_GROUP 8                      // guard-band granularity: samples per re-evaluated group
+#define RD_GROUPS (RD_RUN / RD_GROUP)   // groups per run (one output byte each)
+
 struct rd_run_result {
-    uint32_t word;  // bit r = sign bit of num[t0 + r]   (1 = negative, py:98)
-    float fmax;     // max |component| of f_hat over f[t0-1 .. t0+31]
-    float nmin;     // min |num_hat| over the run
+    uint32_t word;           // bit r = sign bit of num[t0 + r]   (1 = negative, py:98)
+    float fmax;              // max |component| of f_hat over f[t0-1 .. t0+31]
+    float nmin[RD_GROUPS];   // min |num_hat| over each group of 8 samples
 };
+
+// bit g set = group g (samples t0+8g .. t0+8g+7) must be re-evaluated exactly
+RD_HD uint32_t rd_guard_mask(const rd_run_result &r);
 
 // Signs of rot = j^p applied to (I, Q):  p=0 ( I, Q)  p=1 (-Q, I)  p=2 (-I,-Q)  p=3 ( Q,-I).
 // With w = (I,Q) for even p and (Q,I) for odd p, y = (sr*w.x, si*w.y):
@@ -103,6 +115,28 @@ RD_HD uint32_t rd_bitrev32(uint32_t v) {
 #endif
 }
 
+// max(m, |x|, |y|) and min(m, |a|, |b|) as ONE instruction each.  Written with fmaxf/fminf the
+// compiler adds a canonicalising v_max_f32 per operand (three slow-pipe ops per sample instead
+// of one); the operands here are never NaN-sensitive (a NaN ends up flagged by rd_guard_mask).
+RD_HD float rd_max3abs(float m, float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(x), "v"(y));
+    return r;
+#else
+    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)));
+#endif
+}
+RD_HD float rd_min3abs(float m, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)));
+#endif
+}
+
 // (word << 1) | signbit(num)
 RD_HD uint32_t rd_shift_in_sign(uint32_t word, float num) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -115,19 +149,26 @@ RD_HD uint32_t rd_shift_in_sign(uint32_t word, float num) {
 template <class Src>
 RD_HD rd_run_result rd_fast_run(const Src &win) {
     rd_f2 w[RD_WIN];
+    // sample i of the window is converted right before its first use (keeps ~10 samples live)
+#define RD_CONVERT(i)                                                                         \
+    do {                                                                                      \
+        const float kI_ = win.f(2 * (i)), kQ_ = win.f(2 * (i) + 1);                           \
+        if (((i) + 2) & 1) { w[i].x = kQ_; w[i].y = kI_; } else { w[i].x = kI_; w[i].y = kQ_; } \
+    } while (0)
 #pragma unroll
-    for (int i = 0; i < RD_WIN; i++) {
-        const int p = (i + 2) & 3;  // phase of sample t0-10+i
-        const float kI = win.f(2 * i), kQ = win.f(2 * i + 1);
-        if (p & 1) { w[i].x = kQ; w[i].y = kI; } else { w[i].x = kI; w[i].y = kQ; }
-    }
+    for (int i = 0; i < 8; i++) RD_CONVERT(i);
     const float c[5] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4};
     rd_run_result out;
     uint32_t word = 0;
-    float fmaxv = 0.0f, nminv = 3.0e38f;
+    float fmaxv = 0.0f;
+    float nminv[RD_GROUPS];
+#pragma unroll
+    for (int g = 0; g < RD_GROUPS; g++) nminv[g] = 3.0e38f;
     rd_f2 prev = {0.0f, 0.0f};
+    float num_even = 0.0f;
 #pragma unroll
     for (int r = -1; r < RD_RUN; r++) {
+        RD_CONVERT(r + 9);
         // f[t0+r] = sum_m c_m y[t0+r-9+m]; window index of tap m is i = r+1+m
         const int q = (r + 3 + 4) & 3;  // (t-9) mod 4 for the DC term
         // (1+j) j^q : q0 (1,1) q1 (-1,1) q2 (-1,-1) q3 (1,-1); acc starts at -D
@@ -149,20 +190,32 @@ RD_HD rd_run_result rd_fast_run(const Src &win) {
             acc.x = __builtin_fmaf(c[4] * rd_sr(pc), w[ic].x, acc.x);
             acc.y = __builtin_fmaf(c[4] * rd_si(pc), w[ic].y, acc.y);
         }
-        fmaxv = __builtin_fmaxf(fmaxv, __builtin_fmaxf(__builtin_fabsf(acc.x), __builtin_fabsf(acc.y)));
+        fmaxv = rd_max3abs(fmaxv, acc.x, acc.y);
         if (r >= 0) {
             // numerator of py:89: imag_n*real_np - real_n*imag_np, n = f[t-1], np = f[t]
             const float num = __builtin_fmaf(-prev.x, acc.y, prev.y * acc.x);
-            nminv = __builtin_fminf(nminv, __builtin_fabsf(num));
+            if (r & 1) nminv[r / RD_GROUP] = rd_min3abs(nminv[r / RD_GROUP], num_even, num);
+            else num_even = num;
             // shift the sign bit in at the bottom (one v_alignbit_b32); reversed after the loop
             word = rd_shift_in_sign(word, num);
         }
         prev = acc;
+        RD_SCHED_FENCE();  // keep conversions next to their first use (register pressure)
     }
+#undef RD_CONVERT
     out.word = rd_bitrev32(word);  // bit r = sign of num[t0+r]
     out.fmax = fmaxv;
-    out.nmin = nminv;
+#pragma unroll
+    for (int g = 0; g < RD_GROUPS; g++) out.nmin[g] = nminv[g];
     return out;
+}
+
+RD_HD uint32_t rd_guard_mask(const rd_run_result &r) {
+    const float thr = rd_run_threshold(r.fmax);
+    uint32_t m = 0;
+#pragma unroll
+    for (int g = 0; g < RD_GROUPS; g++) m |= (r.nmin[g] > thr) ? 0u : (1u << g);  // NaN -> flagged
+    return m;
 }
 
 // ---- exact evaluation ---------------------------------------------------------------
@@ -273,11 +326,17 @@ RD_HD rd_d2 rd_rot_f64(double a, double b, long n) {
     return y;
 }
 
+// py:26 lut[k] = (k - 127.4) / 127.6.  Evaluated here as (k - 127.4) * (1/127.6): at most 1 ulp
+// from the reference's quotient, which only feeds values compared with a tolerance
+// (filtered 1e-14, discriminated 1e-5 relative, RSSI/SNR 1e-3 dB) - never a sign decision,
+// those use the exact integer path.  A float64 divide per sample is ~10x slower.
+RD_HD double rd_lut(int k) { return ((double)k - 127.4) * (1.0 / 127.6); }
+
 RD_HD rd_d2 rd_sample_f64(const rd_stream_view &v, long n) {
     rd_d2 y = {0.0, 0.0};
     if (n < v.valid_from) return y;
     const uint8_t *p = v.base + 2 * n;
-    return rd_rot_f64(((double)p[0] - 127.4) / 127.6, ((double)p[1] - 127.4) / 127.6, n);  // py:26
+    return rd_rot_f64(rd_lut(p[0]), rd_lut(p[1]), n);
 }
 
 // complex128 input (py:144-150): interleaved re,im doubles

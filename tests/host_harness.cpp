@@ -8,8 +8,9 @@
 
 extern "C" {
 
-// Fast path over a whole stream from reset.  words[n/32]; flagged[n/32] = 1 where the run
-// must be re-evaluated exactly (guard band, or run 0 whose history is the zero state).
+// Fast path over a whole stream from reset.  words[n/32]; flagged[n/32] = 4-bit mask of the
+// 8-sample groups that must be re-evaluated exactly (guard band; run 0, whose history is the
+// zero state, is always re-evaluated whole).
 long hh_fast_stream(const uint8_t *iq, long n, uint32_t *words, uint8_t *flagged) {
     long nflag = 0;
     for (long t0 = 0; t0 + RD_RUN <= n; t0 += RD_RUN) {
@@ -22,11 +23,17 @@ long hh_fast_stream(const uint8_t *iq, long n, uint32_t *words, uint8_t *flagged
         rd_ptr_src src = {win};
         rd_run_result r = rd_fast_run(src);
         words[t0 / RD_RUN] = r.word;
-        uint8_t f = (t0 == 0) || !(r.nmin > rd_run_threshold(r.fmax));
+        uint8_t f = (t0 == 0) ? 0xF : (uint8_t)rd_guard_mask(r);
         flagged[t0 / RD_RUN] = f;
-        nflag += f;
+        nflag += __builtin_popcount(f);
     }
     return nflag;
+}
+
+// exact bits of one 8-sample group (what k_fixup stores as one byte)
+uint8_t hh_exact_group(const uint8_t *iq, long n, long t0) {
+    rd_stream_view v = {iq, 0, n};
+    return (uint8_t)rd_exact_run(v, t0, (int)(n - t0 < RD_GROUP ? n - t0 : RD_GROUP));
 }
 
 void hh_exact_stream(const uint8_t *iq, long n, uint32_t *words) {
