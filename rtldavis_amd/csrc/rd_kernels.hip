@@ -66,10 +66,13 @@ __device__ __forceinline__ void rd_flush_pending(const uint32_t *pend, uint32_t 
 // tile.  Lane L then finds its four chunks 4L..4L+3 at slots 64(L/16) + 16i + L%16 - for a
 // fixed i, 16 neighbouring lanes read 16 neighbouring slots: ds_read_b128 without bank
 // conflicts (a plain linear image would be a 4-way conflict at the 64-byte lane stride).
+__device__ int rd_dbg_variant = 0;  // timing experiments only (RD_K1_VARIANT): 1 = linear source, 2 = no halo load
+
 __device__ __forceinline__ void rd_issue_tile_loads(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *my,
                                                     int lane) {
     const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
-    const int perm = 4 * (lane & 15) + (lane >> 4);
+    const int variant = rd_dbg_variant;
+    const int perm = (variant & 1) ? lane : 4 * (lane & 15) + (lane >> 4);
 #pragma unroll
     for (int j = 0; j < 4; j++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024 + perm * 16),
@@ -77,12 +80,15 @@ __device__ __forceinline__ void rd_issue_tile_loads(const rd_layout &lay, uint32
     // halo: the 32 bytes before the tile (previous tile, or the caller's history bytes).
     // With zero history there is nothing to read: run 0 is always re-evaluated exactly.
     const bool has_halo = (ti > 0) || lay.hist_mode;
-    if (lane < 2)
+    if (lane < 2 && !(variant & 2))
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)(src + (has_halo ? -32 : 0) + lane * 16),
             (__attribute__((address_space(3))) void *)(my), 16, 0, 0);
 }
 
+// DBG (compile-time, 0 in the shipped instantiation): 1 = no global loads (compute on whatever
+// LDS holds), 2 = loads and LDS reads only, no arithmetic - timing ablations, results are garbage.
+template <int DBG, int NPK>
 __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t tiles_per_stream,
                                                       uint32_t runs_per_stream, uint32_t *fix_list,
                                                       uint32_t fix_cap, uint32_t *counters) {
@@ -106,9 +112,14 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
     const uint8_t *h0 = lane ? my + 32 + 16 * (64 * (pl >> 4) + 32 + (pl & 15)) : my;
     const uint8_t *h1 = lane ? h0 + 256 : my + 16;
 
+    // The packed word of tile i is stored at the start of iteration i+1, BEFORE the next
+    // tile's loads are issued: stores count in vmcnt too, and a store issued after the loads
+    // would make every `s_waitcnt vmcnt(0)` wait for its write latency as well (-20 % measured).
+    uint32_t st_word = 0;
+    uint32_t *st_ptr = nullptr;
     const uint32_t first = blockIdx.x * RD_WAVES + wave;
     uint32_t s = first / tiles_per_stream, ti = first % tiles_per_stream;
-    if (s < (uint32_t)lay.n_streams) rd_issue_tile_loads(lay, s, ti, my, lane);
+    if (DBG != 1 && s < (uint32_t)lay.n_streams) rd_issue_tile_loads(lay, s, ti, my, lane);
     while (s < (uint32_t)lay.n_streams) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile has landed in LDS
         rd_reg_src win;
@@ -125,11 +136,23 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
         // The window is in registers: the same LDS buffer can take the next tile while this
         // one is computed (~2000 VALU instructions cover the HBM latency).
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (st_ptr) *st_ptr = st_word;  // previous tile's output
+        st_ptr = nullptr;
         uint32_t ns = s + dq, nti = ti + dr;
         if (nti >= tiles_per_stream) { nti -= tiles_per_stream; ns++; }
-        if (ns < (uint32_t)lay.n_streams) rd_issue_tile_loads(lay, ns, nti, my, lane);
+        if (DBG != 1 && ns < (uint32_t)lay.n_streams) rd_issue_tile_loads(lay, ns, nti, my, lane);
 
-        const rd_run_result r = rd_fast_run(win);
+        rd_run_result r;
+        if (DBG == 2) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int j = 0; j < 24; j++) x ^= win.q[j];
+            r.word = x; r.fmax = 1.0f;
+#pragma unroll
+            for (int g = 0; g < RD_GROUPS; g++) r.nmin[g] = 1.0e30f;
+        } else {
+            r = rd_fast_run<NPK>(win);
+        }
 
         const uint32_t run = ti * 64 + lane;
         const uint32_t t0 = run * RD_RUN;
@@ -138,7 +161,8 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
             uint32_t word = r.word;
             const uint32_t left = lay.n_samples - t0;
             if (left < RD_RUN) word &= (1u << left) - 1u;
-            lay.bits[(size_t)s * lay.bits_stride + run] = word;
+            st_word = word;
+            st_ptr = &lay.bits[(size_t)s * lay.bits_stride + run];
             gmask = (run == 0 && !lay.hist_mode) ? 0xFu : rd_guard_mask(r);
             if (left < RD_RUN) gmask &= (1u << ((left + RD_GROUP - 1) / RD_GROUP)) - 1u;
         }
@@ -164,6 +188,7 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
         s = ns;
         ti = nti;
     }
+    if (st_ptr) *st_ptr = st_word;
     if (npend) rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
 }
 
@@ -182,8 +207,28 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
     const uint64_t max_wgs = 256ull * per_cu;
     if (wgs > max_wgs) wgs = max_wgs;
     if (wgs == 0) return;
-    hipLaunchKernelGGL(k_demod_bits, dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps, fix_list, fix_cap,
-                       counters);
+    static int dbg = -1, npk = RD_NPK_DEFAULT;
+    if (dbg < 0) {
+        const char *e = getenv("RD_K1_DEBUG");  // timing ablations (see k_demod_bits)
+        dbg = e ? atoi(e) : 0;
+        const char *v = getenv("RD_K1_VARIANT");
+        const int variant = v ? atoi(v) : 0;
+        if (variant) hipMemcpyToSymbol(HIP_SYMBOL(rd_dbg_variant), &variant, sizeof(int));
+        const char *n = getenv("RD_K1_NPK");  // packed FIR steps per output, for tuning sweeps
+        if (n) npk = atoi(n);
+    }
+#define RD_LAUNCH_K1(D, N) \
+    hipLaunchKernelGGL((k_demod_bits<D, N>), dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps, fix_list, fix_cap, counters)
+    if (dbg == 1) RD_LAUNCH_K1(1, RD_NPK_DEFAULT);
+    else if (dbg == 2) RD_LAUNCH_K1(2, RD_NPK_DEFAULT);
+    else if (npk == 0) RD_LAUNCH_K1(0, 0);
+    else if (npk == 2) RD_LAUNCH_K1(0, 2);
+    else if (npk == 4) RD_LAUNCH_K1(0, 4);
+    else if (npk == 6) RD_LAUNCH_K1(0, 6);
+    else if (npk == 7) RD_LAUNCH_K1(0, 7);
+    else if (npk == 9) RD_LAUNCH_K1(0, 9);
+    else RD_LAUNCH_K1(0, RD_NPK_DEFAULT);
+#undef RD_LAUNCH_K1
 }
 
 // ------------------------------------------------------------------------------------------

@@ -66,11 +66,16 @@ RD_HD float rd_run_threshold(float F) {
     return (F * (4.0f * RD_E_ABS + 2.3841858e-7f * F) + 1.0e-7f) * 1.000001f;
 }
 
+// (x, y) = (re, im) or (im, re) of one sample / FIR output.  On the device a 64-bit register
+// pair so that v_pk_add_f32 / v_pk_fma_f32 can take it whole.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float rd_f2 __attribute__((ext_vector_type(2)));
+#else
 struct rd_f2 {
     float x, y;
 };
+#endif
 
-// Result of the fast evaluation of one run.
 #define RD_GROUP 8                      // guard-band granularity: samples per re-evaluated group
 #define RD_GROUPS (RD_RUN / RD_GROUP)   // groups per run (one output byte each)
 
@@ -98,11 +103,152 @@ struct rd_ptr_src {
     RD_HDM float f(int i) const { return (float)p[i]; }
 };
 
-// Issue-pipe note (measured on MI355X, tools/ubench): plain fp32 add/sub/mul/fma issue in
-// 2 cycles per wave64, conversions / min / max / bit-field ops in 4, on a second pipe that
-// overlaps with the first when >= 4 waves share a SIMD; packed fp32 takes 4.  The FIR is
-// therefore written as scalar add/sub + fma (18 + 2 ops on the fast pipe per sample) and
-// conversion, guard (max3 / min) and bit insertion (alignbit) ride on the other pipe.
+// Issue model measured on MI355X (tools/ubench/valu_*.hip, profiles/): a SIMD issues one VALU
+// instruction per 2 cycles whatever its class; the "slow" class (conversions, min/max,
+// alignbit, packed fp32 ...) additionally needs 4 cycles between two of its own.  So the
+// instruction COUNT is what matters as long as slow-class ops stay below half of the mix:
+// RD_NPK of the nine FIR steps per output (4 pair sums, 5 multiply-adds) are issued as packed
+// fp32 (one instruction for re and im), the rest as scalar pairs.  Results are identical
+// either way (same IEEE operations per component).
+#ifndef RD_NPK_DEFAULT
+#define RD_NPK_DEFAULT 5
+#endif
+
+// s = a + b or a - b (exact: small integers)
+template <bool SUB, bool PACKED>
+RD_HD rd_f2 rd_pair(rd_f2 a, rd_f2 b) {
+    rd_f2 s;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (PACKED) {
+        if (SUB) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(s) : "v"(a), "v"(b));
+        else asm("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(a), "v"(b));
+        return s;
+    }
+#endif
+    if (SUB) { s.x = a.x - b.x; s.y = a.y - b.y; } else { s.x = a.x + b.x; s.y = a.y + b.y; }
+    return s;
+}
+
+// acc + (NX ? -c : c) * s.x, acc + (NY ? -c : c) * s.y   (one rounding per component)
+// The packed form writes a fresh register pair (separate output operand) so that a constant
+// `acc` (the DC term of the first tap) needs no copy.
+template <bool NX, bool NY, bool PACKED>
+RD_HD rd_f2 rd_tap(float c, rd_f2 s, rd_f2 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (PACKED) {
+        rd_f2 cc = {c, c};
+        rd_f2 r;
+        if (NX && NY) asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "s"(cc), "v"(s), "v"(acc));
+        else if (NX) asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0]" : "=v"(r) : "s"(cc), "v"(s), "v"(acc));
+        else if (NY) asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,0]" : "=v"(r) : "s"(cc), "v"(s), "v"(acc));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(cc), "v"(s), "v"(acc));
+        return r;
+    }
+#endif
+    acc.x = __builtin_fmaf(NX ? -c : c, s.x, acc.x);
+    acc.y = __builtin_fmaf(NY ? -c : c, s.y, acc.y);
+    return acc;
+}
+
+// One FIR output f[t0+R] (R = -1..31) from the converted window w[]: compile-time R so that
+// every phase, sign and tap is a constant.
+template <int R, int RD_NPK>
+RD_HD rd_f2 rd_fir_out(const rd_f2 *w) {
+    // f[t0+R] = sum_m c_m y[t0+R-9+m]; window index of tap m is i = R+1+m
+    constexpr int q = (R + 3 + 4) & 3;  // (t-9) mod 4 for the DC term
+    // (1+j) j^q : q0 (1,1) q1 (-1,1) q2 (-1,-1) q3 (1,-1); acc starts at -D
+    rd_f2 acc;
+    acc.x = (q == 1 || q == 2) ? RD_DC : -RD_DC;
+    acc.y = (q == 2 || q == 3) ? RD_DC : -RD_DC;
+    // phase p of sample i: signs sr(p) = -1 for p in {1,2}, si(p) = -1 for p in {2,3}
+#define RD_PH(i) (((i) + 2) & 3)
+#define RD_NX(i) (RD_PH(i) == 1 || RD_PH(i) == 2)
+#define RD_NY(i) (RD_PH(i) == 2 || RD_PH(i) == 3)
+    // packed steps are spread over the nine: pair sums first (0..3), then taps 0..4
+    const rd_f2 s0 = rd_pair<false, (RD_NPK > 0)>(w[R + 1], w[R + 9]);
+    const rd_f2 s1 = rd_pair<true, (RD_NPK > 1)>(w[R + 2], w[R + 8]);
+    const rd_f2 s2 = rd_pair<false, (RD_NPK > 2)>(w[R + 3], w[R + 7]);
+    const rd_f2 s3 = rd_pair<true, (RD_NPK > 3)>(w[R + 4], w[R + 6]);
+    acc = rd_tap<RD_NX(R + 1), RD_NY(R + 1), (RD_NPK > 4)>((float)RD_C0, s0, acc);
+    acc = rd_tap<RD_NX(R + 2), RD_NY(R + 2), (RD_NPK > 5)>((float)RD_C1, s1, acc);
+    acc = rd_tap<RD_NX(R + 3), RD_NY(R + 3), (RD_NPK > 6)>((float)RD_C2, s2, acc);
+    acc = rd_tap<RD_NX(R + 4), RD_NY(R + 4), (RD_NPK > 7)>((float)RD_C3, s3, acc);
+    acc = rd_tap<RD_NX(R + 5), RD_NY(R + 5), (RD_NPK > 8)>((float)RD_C4, w[R + 5], acc);
+#undef RD_PH
+#undef RD_NX
+#undef RD_NY
+    return acc;
+}
+
+RD_HD float rd_max3abs(float m, float x, float y);
+RD_HD float rd_min3abs(float m, float a, float b);
+RD_HD uint32_t rd_shift_in_sign(uint32_t word, float num);
+RD_HD uint32_t rd_bitrev32(uint32_t v);
+
+struct rd_run_state {
+    rd_f2 prev;
+    float fmaxv, num_even;
+    float nminv[RD_GROUPS];
+    uint32_t word;
+};
+
+// output R of the run: FIR, guard statistics, sign bit
+template <int R, int NPK, class Src>
+RD_HD void rd_fast_step(const Src &win, rd_f2 *w, rd_run_state &st) {
+    {   // sample R+9 of the window is converted right before its first use
+        constexpr int i = R + 9;
+        const float kI = win.f(2 * i), kQ = win.f(2 * i + 1);
+        if ((i + 2) & 1) { w[i].x = kQ; w[i].y = kI; } else { w[i].x = kI; w[i].y = kQ; }
+    }
+    const rd_f2 acc = rd_fir_out<R, NPK>(w);
+    st.fmaxv = rd_max3abs(st.fmaxv, acc.x, acc.y);
+    if (R >= 0) {
+        // numerator of py:89: imag_n*real_np - real_n*imag_np, n = f[t-1], np = f[t]
+        const float num = __builtin_fmaf(-st.prev.x, acc.y, st.prev.y * acc.x);
+        if (R & 1) st.nminv[(R < 0 ? 0 : R) / RD_GROUP] = rd_min3abs(st.nminv[(R < 0 ? 0 : R) / RD_GROUP], st.num_even, num);
+        else st.num_even = num;
+        st.word = rd_shift_in_sign(st.word, num);  // one v_alignbit_b32; reversed after the loop
+    }
+    st.prev = acc;
+    RD_SCHED_FENCE();  // keep conversions next to their first use (register pressure)
+}
+
+template <int R, int NPK, class Src>
+struct rd_fast_unroll {
+    static RD_HDM void run(const Src &win, rd_f2 *w, rd_run_state &st) {
+        rd_fast_step<R, NPK>(win, w, st);
+        rd_fast_unroll<R + 1, NPK, Src>::run(win, w, st);
+    }
+};
+template <int NPK, class Src>
+struct rd_fast_unroll<RD_RUN, NPK, Src> {
+    static RD_HDM void run(const Src &, rd_f2 *, rd_run_state &) {}
+};
+
+// Fast fp32 evaluation of one run.  `win` holds the raw bytes of samples t0-10 .. t0+30
+// (2*RD_WIN bytes, I then Q); t0 % 4 == 0 in absolute stream time.
+template <int NPK = RD_NPK_DEFAULT, class Src>
+RD_HD rd_run_result rd_fast_run(const Src &win) {
+    rd_f2 w[RD_WIN];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float kI = win.f(2 * i), kQ = win.f(2 * i + 1);
+        if ((i + 2) & 1) { w[i].x = kQ; w[i].y = kI; } else { w[i].x = kI; w[i].y = kQ; }
+    }
+    rd_run_state st;
+    st.prev.x = 0.0f; st.prev.y = 0.0f;
+    st.fmaxv = 0.0f; st.num_even = 0.0f; st.word = 0;
+#pragma unroll
+    for (int g = 0; g < RD_GROUPS; g++) st.nminv[g] = 3.0e38f;
+    rd_fast_unroll<-1, NPK, Src>::run(win, w, st);
+    rd_run_result out;
+    out.word = rd_bitrev32(st.word);  // bit r = sign of num[t0+r]
+    out.fmax = st.fmaxv;
+#pragma unroll
+    for (int g = 0; g < RD_GROUPS; g++) out.nmin[g] = st.nminv[g];
+    return out;
+}
+
 RD_HD uint32_t rd_bitrev32(uint32_t v) {
 #if defined(__clang__)
     return __builtin_bitreverse32(v);
@@ -144,70 +290,6 @@ RD_HD uint32_t rd_shift_in_sign(uint32_t word, float num) {
 #else
     return (word << 1) | (__builtin_bit_cast(uint32_t, num) >> 31);
 #endif
-}
-
-template <class Src>
-RD_HD rd_run_result rd_fast_run(const Src &win) {
-    rd_f2 w[RD_WIN];
-    // sample i of the window is converted right before its first use (keeps ~10 samples live)
-#define RD_CONVERT(i)                                                                         \
-    do {                                                                                      \
-        const float kI_ = win.f(2 * (i)), kQ_ = win.f(2 * (i) + 1);                           \
-        if (((i) + 2) & 1) { w[i].x = kQ_; w[i].y = kI_; } else { w[i].x = kI_; w[i].y = kQ_; } \
-    } while (0)
-#pragma unroll
-    for (int i = 0; i < 8; i++) RD_CONVERT(i);
-    const float c[5] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4};
-    rd_run_result out;
-    uint32_t word = 0;
-    float fmaxv = 0.0f;
-    float nminv[RD_GROUPS];
-#pragma unroll
-    for (int g = 0; g < RD_GROUPS; g++) nminv[g] = 3.0e38f;
-    rd_f2 prev = {0.0f, 0.0f};
-    float num_even = 0.0f;
-#pragma unroll
-    for (int r = -1; r < RD_RUN; r++) {
-        RD_CONVERT(r + 9);
-        // f[t0+r] = sum_m c_m y[t0+r-9+m]; window index of tap m is i = r+1+m
-        const int q = (r + 3 + 4) & 3;  // (t-9) mod 4 for the DC term
-        // (1+j) j^q : q0 (1,1) q1 (-1,1) q2 (-1,-1) q3 (1,-1); acc starts at -D
-        rd_f2 acc;
-        acc.x = (q == 1 || q == 2) ? RD_DC : -RD_DC;
-        acc.y = (q == 2 || q == 3) ? RD_DC : -RD_DC;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int ia = r + 1 + k, ib = r + 9 - k;
-            const int pa = (ia + 2) & 3;
-            rd_f2 s;
-            if (k & 1) { s.x = w[ia].x - w[ib].x; s.y = w[ia].y - w[ib].y; }
-            else       { s.x = w[ia].x + w[ib].x; s.y = w[ia].y + w[ib].y; }
-            acc.x = __builtin_fmaf(c[k] * rd_sr(pa), s.x, acc.x);
-            acc.y = __builtin_fmaf(c[k] * rd_si(pa), s.y, acc.y);
-        }
-        {
-            const int ic = r + 5, pc = (ic + 2) & 3;
-            acc.x = __builtin_fmaf(c[4] * rd_sr(pc), w[ic].x, acc.x);
-            acc.y = __builtin_fmaf(c[4] * rd_si(pc), w[ic].y, acc.y);
-        }
-        fmaxv = rd_max3abs(fmaxv, acc.x, acc.y);
-        if (r >= 0) {
-            // numerator of py:89: imag_n*real_np - real_n*imag_np, n = f[t-1], np = f[t]
-            const float num = __builtin_fmaf(-prev.x, acc.y, prev.y * acc.x);
-            if (r & 1) nminv[r / RD_GROUP] = rd_min3abs(nminv[r / RD_GROUP], num_even, num);
-            else num_even = num;
-            // shift the sign bit in at the bottom (one v_alignbit_b32); reversed after the loop
-            word = rd_shift_in_sign(word, num);
-        }
-        prev = acc;
-        RD_SCHED_FENCE();  // keep conversions next to their first use (register pressure)
-    }
-#undef RD_CONVERT
-    out.word = rd_bitrev32(word);  // bit r = sign of num[t0+r]
-    out.fmax = fmaxv;
-#pragma unroll
-    for (int g = 0; g < RD_GROUPS; g++) out.nmin[g] = nminv[g];
-    return out;
 }
 
 RD_HD uint32_t rd_guard_mask(const rd_run_result &r) {
