@@ -87,6 +87,15 @@ extern "C" int rd_set_device(int device) {
 // Wait for a stream by polling.  The runtime's blocking waits (hipStreamSynchronize, synchronous
 // hipMemcpy) were measured to add 10-20 ms of wake-up latency per call on this platform, an
 // order of magnitude more than a whole batch takes on the GPU.
+static int wait_event(hipEvent_t ev) {
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return RD_OK;
+        if (e != hipErrorNotReady) return fail(RD_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(e));
+        __builtin_ia32_pause();
+    }
+}
+
 static int wait_stream(hipStream_t st) {
     for (;;) {
         const hipError_t e = hipStreamQuery(st);
@@ -135,42 +144,62 @@ static int make_devcfg(const rd_config *c, rd_devcfg *d) {
 
 // Reference order inside one call: search is phase-major then ascending (py:175-186),
 // slice keeps the first occurrence of each byte string (py:203-205).
-// Records are ordered by (stream, call, index % S, index): small lists with std::sort, large
-// ones with stable LSD counting passes over an index array (a comparison sort that moves
-// 64-byte records costs tens of milliseconds at 2e4 packets).
-static void order_and_dedupe(std::vector<rd_packet> &recs, int S) {
-    const size_t n = recs.size();
+// Records are ordered by (stream, call, index % S, index).  Small lists: std::sort.  Large
+// lists: the key is packed into 64 bits (when the field widths allow) and sorted with LSD
+// counting passes over (key, index) pairs - a comparison sort that moves 64-byte records costs
+// tens of milliseconds at 7e4 records.  `recs` may be pinned memory; output goes to `out`.
+static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector<rd_packet> &out) {
+    out.clear();
     if (n == 0) return;
     std::vector<uint32_t> idx(n);
     for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
-    if (n < 256) {
-        std::sort(idx.begin(), idx.end(), [&](uint32_t ia, uint32_t ib) {
-            const rd_packet &a = recs[ia], &b = recs[ib];
-            if (a.stream != b.stream) return a.stream < b.stream;
-            if (a.call != b.call) return a.call < b.call;
-            const int pa = a.index % S, pb = b.index % S;
-            if (pa != pb) return pa < pb;
-            return a.index < b.index;
-        });
+    auto less = [&](uint32_t ia, uint32_t ib) {
+        const rd_packet &a = recs[ia], &b = recs[ib];
+        if (a.stream != b.stream) return a.stream < b.stream;
+        if (a.call != b.call) return a.call < b.call;
+        const int pa = a.index % S, pb = b.index % S;
+        if (pa != pb) return pa < pb;
+        return a.index < b.index;
+    };
+    if (n < 512) {
+        std::sort(idx.begin(), idx.end(), less);
     } else {
-        std::vector<uint32_t> tmp(n), count;
-        auto pass = [&](auto digit) {  // one stable counting pass on a 16-bit digit
-            count.assign((1u << 16) + 1, 0);
-            for (size_t i = 0; i < n; i++) count[digit(recs[idx[i]]) + 1]++;
-            for (uint32_t d = 0; d < (1u << 16); d++) count[d + 1] += count[d];
-            for (size_t i = 0; i < n; i++) tmp[count[digit(recs[idx[i]])]++] = idx[i];
-            idx.swap(tmp);
-        };
-        auto by_field = [&](auto field) {  // non-negative 32-bit field, low digit first
-            pass([&](const rd_packet &r) { return (uint32_t)field(r) & 0xFFFFu; });
-            pass([&](const rd_packet &r) { return (uint32_t)field(r) >> 16; });
-        };
-        by_field([](const rd_packet &r) { return r.index; });
-        pass([S](const rd_packet &r) { return (uint32_t)(r.index % S) & 0xFFFFu; });
-        by_field([](const rd_packet &r) { return r.call; });
-        by_field([](const rd_packet &r) { return r.stream; });
+        // field widths
+        uint32_t max_stream = 0, max_call = 0, max_index = 0;
+        for (size_t i = 0; i < n; i++) {
+            max_stream = std::max(max_stream, (uint32_t)recs[i].stream);
+            max_call = std::max(max_call, (uint32_t)recs[i].call);
+            max_index = std::max(max_index, (uint32_t)recs[i].index);
+        }
+        auto bits_for = [](uint32_t v) { int b = 1; while (b < 32 && (v >> b)) b++; return b; };
+        const int bi = bits_for(max_index), bp = bits_for((uint32_t)(S - 1)), bc = bits_for(max_call),
+                  bs = bits_for(max_stream);
+        if (bi + bp + bc + bs <= 64) {
+            std::vector<uint64_t> key(n), ktmp(n);
+            std::vector<uint32_t> itmp(n);
+            for (size_t i = 0; i < n; i++) {
+                const rd_packet &r = recs[i];
+                key[i] = ((((uint64_t)(uint32_t)r.stream << bc | (uint32_t)r.call) << bp | (uint32_t)(r.index % S)) << bi) |
+                         (uint32_t)r.index;
+            }
+            const int total_bits = bi + bp + bc + bs;
+            uint32_t count[2049];
+            for (int shift = 0; shift < total_bits; shift += 11) {
+                memset(count, 0, sizeof count);
+                for (size_t i = 0; i < n; i++) count[((key[i] >> shift) & 2047) + 1]++;
+                for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+                for (size_t i = 0; i < n; i++) {
+                    const uint32_t pos = count[(key[i] >> shift) & 2047]++;
+                    ktmp[pos] = key[i];
+                    itmp[pos] = idx[i];
+                }
+                key.swap(ktmp);
+                idx.swap(itmp);
+            }
+        } else {
+            std::sort(idx.begin(), idx.end(), less);
+        }
     }
-    std::vector<rd_packet> out;
     out.reserve(n);
     size_t group = 0;
     for (size_t i = 0; i < n; i++) {
@@ -180,7 +209,6 @@ static void order_and_dedupe(std::vector<rd_packet> &recs, int S) {
         for (size_t k = group; k < out.size() && !dup; k++) dup = memcmp(out[k].data, r.data, (size_t)r.nbytes) == 0;
         if (!dup) out.push_back(r);
     }
-    recs.swap(out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -203,6 +231,8 @@ struct rd_batch {
     std::vector<hipEvent_t> evs;  // 5 events per timed run, read back in rd_batch_get_timing
     size_t ev_runs = 0;           // timed runs recorded since the last rd_batch_get_timing
     hipEvent_t *ev = nullptr;     // the current run's five events
+    hipEvent_t done = nullptr;    // recorded after the run's readback copies: results wait on it,
+                                  // not on the stream, so another batch may already be queued behind
     uint32_t h_cnt[RD_CNT_SLOTS] = {};
     uint32_t *h_cnt_pin = nullptr;   // pinned: counters of the run in flight
     rd_packet *h_recs_pin = nullptr; // pinned: records of the run in flight (rec_cap entries)
@@ -267,6 +297,7 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipHostMalloc((void **)&b->h_cnt_pin, RD_CNT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     b->rec_pin_cap = b->rec_cap;
+    HIPCHK(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     b->dev_ready = true;
     return RD_OK;
 }
@@ -277,6 +308,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
+        if (b->done) hipEventDestroy(b->done);
         for (auto &e : b->evs) if (e) hipEventDestroy(e);
     }
     delete b;
@@ -317,6 +349,7 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     hipMemcpyAsync(b->h_cnt_pin, b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
     const uint32_t spec = std::min(b->rec_cap, b->spec_recs);
     if (spec) hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st);
+    hipEventRecord(b->done, st);
 }
 
 extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
@@ -353,7 +386,7 @@ static int batch_finish(rd_batch *b) {
     hipStream_t st = b->stream;
     for (int attempt = 0; attempt < 8; attempt++) {
         const double ta = now_ms();
-        int wrc = wait_stream(st);
+        int wrc = wait_event(b->done);
         if (wrc) return wrc;
         memcpy(b->h_cnt, b->h_cnt_pin, sizeof b->h_cnt);
         if (dbg_host()) fprintf(stderr, "[rd] finish: wait %.3f ms\n", now_ms() - ta);
@@ -403,9 +436,9 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
         if (rc) return rc;
     }
     b->spec_recs = std::max<uint32_t>(1024, nrec + nrec / 4);
-    std::vector<rd_packet> recs(b->h_recs_pin, b->h_recs_pin + nrec);
+    std::vector<rd_packet> recs;
     const double t2 = now_ms();
-    order_and_dedupe(recs, b->dc.S);
+    order_and_dedupe(b->h_recs_pin, nrec, b->dc.S, recs);
     if (dbg_host())
         fprintf(stderr, "[rd] results: finish %.3f ms, D2H %u recs %.3f ms, order+dedupe %.3f ms\n", t1 - t0, nrec,
                 t2 - t1, now_ms() - t2);
@@ -691,8 +724,8 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
         rc = copy_d2h(h->h_recs + spec, h->d_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
         if (rc) return rc;
     }
-    std::vector<rd_packet> recs(h->h_recs, h->h_recs + nrec);
-    order_and_dedupe(recs, h->dc.S);
+    std::vector<rd_packet> recs;
+    order_and_dedupe(h->h_recs, nrec, h->dc.S, recs);
     *n = (int)recs.size();
     if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
     if (!recs.empty()) {

@@ -511,6 +511,67 @@ __device__ __forceinline__ void rd_rssi_record(const View &v, long origin, const
     }
 }
 
+// uint8 input: the window means are evaluated in fp32 (|f|^2 to ~1e-6 relative, 4e-6 dB; the
+// tolerance on RSSI/SNR is 1e-3 dB).  Each lane takes a contiguous slice of the window so the
+// nine-sample FIR history slides through registers (15 conversions for 7 outputs).
+__device__ __forceinline__ void rd_rssi_record_u8(const rd_stream_view &v, long origin, const rd_devcfg &cfg,
+                                                  rd_packet *o, int lane) {
+    const long q = o->index;
+    const long ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
+    const long pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
+    const long per = (pe - ns + 63) / 64;  // outputs per lane
+    const long j0 = ns + per * lane;
+    const long j1 = j0 + per < pe ? j0 + per : pe;
+    const float c[9] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4,
+                        (float)RD_C3, (float)RD_C2, (float)RD_C1, (float)RD_C0};
+    float wr[9], wi[9];  // y[t-9 .. t-1] for the next output t
+    float noise = 0.0f, sig = 0.0f;
+    if (j0 < j1) {
+        const long t0 = origin + j0 - 1;  // first output index
+#pragma unroll
+        for (int m = 0; m < 9; m++) {
+            const long n = t0 - 9 + m;
+            float a = 0.0f, b = 0.0f;
+            if (n >= v.valid_from) {
+                a = ((float)v.base[2 * n] - 127.4f) * (1.0f / 127.6f);
+                b = ((float)v.base[2 * n + 1] - 127.4f) * (1.0f / 127.6f);
+            }
+            const int ph = (int)(n & 3);
+            wr[m] = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
+            wi[m] = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
+        }
+        for (long j = j0; j < j1; j++) {
+            float fr = 0.0f, fi = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 9; m++) {
+                fr = __builtin_fmaf(c[m], wr[m], fr);
+                fi = __builtin_fmaf(c[m], wi[m], fi);
+            }
+            const float pw = fr * fr + fi * fi;
+            if (j < q) noise += pw; else sig += pw;
+            // slide: the next output also uses the sample at index t-1+1 = origin + j - 1
+            const long n = origin + j - 1;
+#pragma unroll
+            for (int m = 0; m < 8; m++) { wr[m] = wr[m + 1]; wi[m] = wi[m + 1]; }
+            float a = 0.0f, b = 0.0f;
+            if (n >= v.valid_from) {
+                a = ((float)v.base[2 * n] - 127.4f) * (1.0f / 127.6f);
+                b = ((float)v.base[2 * n + 1] - 127.4f) * (1.0f / 127.6f);
+            }
+            const int ph = (int)(n & 3);
+            wr[8] = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
+            wi[8] = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
+        }
+    }
+    const double noise_d = rd_wave_sum((double)noise), sig_d = rd_wave_sum((double)sig);
+    if (lane == 0) {
+        const double noise_power = (q > ns) ? noise_d / (double)(q - ns) : 1e-9;
+        const double signal_power = (pe > q) ? sig_d / (double)(pe - q) : __builtin_nan("");
+        o->rssi = signal_power > 0 ? 10.0 * log10(signal_power) : -120.0;
+        o->snr = noise_power > 0 ? 10.0 * log10(signal_power / noise_power) : 50.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rssi(rd_layout lay, rd_devcfg cfg, int batch_mode, rd_packet *recs,
                                               uint32_t rec_cap, const uint32_t *counters) {
     const int lane = threadIdx.x & 63;
@@ -523,7 +584,7 @@ __global__ __launch_bounds__(256) void k_rssi(rd_layout lay, rd_devcfg cfg, int 
         v.base = lay.iq + (size_t)o->stream * lay.stream_stride;
         v.valid_from = lay.valid_from;
         v.n = lay.n_samples;
-        rd_rssi_record(v, batch_mode ? (long)o->call * cfg.B : 0, cfg, o, lane);
+        rd_rssi_record_u8(v, batch_mode ? (long)o->call * cfg.B : 0, cfg, o, lane);
     }
 }
 
