@@ -66,13 +66,10 @@ __device__ __forceinline__ void rd_flush_pending(const uint32_t *pend, uint32_t 
 // tile.  Lane L then finds its four chunks 4L..4L+3 at slots 64(L/16) + 16i + L%16 - for a
 // fixed i, 16 neighbouring lanes read 16 neighbouring slots: ds_read_b128 without bank
 // conflicts (a plain linear image would be a 4-way conflict at the 64-byte lane stride).
-__device__ int rd_dbg_variant = 0;  // timing experiments only (RD_K1_VARIANT): 1 = linear source, 2 = no halo load
-
 __device__ __forceinline__ void rd_issue_tile_loads(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *my,
                                                     int lane) {
     const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
-    const int variant = rd_dbg_variant;
-    const int perm = (variant & 1) ? lane : 4 * (lane & 15) + (lane >> 4);
+    const int perm = 4 * (lane & 15) + (lane >> 4);
 #pragma unroll
     for (int j = 0; j < 4; j++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024 + perm * 16),
@@ -80,7 +77,7 @@ __device__ __forceinline__ void rd_issue_tile_loads(const rd_layout &lay, uint32
     // halo: the 32 bytes before the tile (previous tile, or the caller's history bytes).
     // With zero history there is nothing to read: run 0 is always re-evaluated exactly.
     const bool has_halo = (ti > 0) || lay.hist_mode;
-    if (lane < 2 && !(variant & 2))
+    if (lane < 2)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void *)(src + (has_halo ? -32 : 0) + lane * 16),
             (__attribute__((address_space(3))) void *)(my), 16, 0, 0);
@@ -211,9 +208,6 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
     if (dbg < 0) {
         const char *e = getenv("RD_K1_DEBUG");  // timing ablations (see k_demod_bits)
         dbg = e ? atoi(e) : 0;
-        const char *v = getenv("RD_K1_VARIANT");
-        const int variant = v ? atoi(v) : 0;
-        if (variant) hipMemcpyToSymbol(HIP_SYMBOL(rd_dbg_variant), &variant, sizeof(int));
         const char *n = getenv("RD_K1_NPK");  // packed FIR steps per output, for tuning sweeps
         if (n) npk = atoi(n);
     }

@@ -111,7 +111,7 @@ struct rd_ptr_src {
 // fp32 (one instruction for re and im), the rest as scalar pairs.  Results are identical
 // either way (same IEEE operations per component).
 #ifndef RD_NPK_DEFAULT
-#define RD_NPK_DEFAULT 5
+#define RD_NPK_DEFAULT 0
 #endif
 
 // s = a + b or a - b (exact: small integers)

@@ -1,0 +1,44 @@
+"""A/B timing of k_demod_bits variants under continuous load (diagnostic).
+Each variant is selected through an environment variable read at library load, so every
+variant runs in its own subprocess; all share one GPU box and are interleaved round-robin.
+usage: k1_ab.py 'NAME=ENV1=V1,ENV2=V2' ...   (NAME alone = defaults)"""
+import json, os, subprocess, sys
+
+CHILD = r'''
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[0]))) if False else os.getcwd())
+import numpy as np
+from rtldavis_amd import batch, dsp, synth
+cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 8192)
+uniq = synth.synth_streams(range(64))
+host = np.tile(uniq, (64, 1))
+bd = batch.BatchDemodulator(cfg, 4096, 33)
+bd.upload(host)
+bd.set_timing(True)
+for _ in range(10): bd.run()
+bd.results(); bd.timing()
+for _ in range(40): bd.run()
+bd.results()
+print(json.dumps(bd.timing()))
+'''
+
+def main():
+    variants = []
+    for a in sys.argv[1:]:
+        name, _, envs = a.partition("=")
+        env = dict(kv.split("=", 1) for kv in envs.split(",") if kv) if envs else {}
+        variants.append((name, env))
+    res = {n: [] for n, _ in variants}
+    for rnd in range(3):
+        for name, env in variants:
+            e = dict(os.environ); e.update(env)
+            out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True, cwd=os.getcwd())
+            try:
+                t = json.loads(out.stdout.strip().splitlines()[-1])
+                res[name].append(t["demod_ms"])
+            except Exception:
+                print(name, "FAILED", out.stderr[-400:])
+    for name, v in res.items():
+        print(f"{name:24s} demod_ms min {min(v):.4f}  med {sorted(v)[len(v)//2]:.4f}  all {['%.4f' % x for x in v]}")
+
+main()
