@@ -233,6 +233,8 @@ struct rd_batch {
     hipEvent_t *ev = nullptr;     // the current run's five events
     hipEvent_t done = nullptr;    // recorded after the run's readback copies: results wait on it,
                                   // not on the stream, so another batch may already be queued behind
+    hipEvent_t kdone = nullptr;   // recorded after the run's last kernel
+    hipStream_t copy_stream = nullptr;  // readback runs here, beside the next batch's kernels
     uint32_t h_cnt[RD_CNT_SLOTS] = {};
     uint32_t *h_cnt_pin = nullptr;   // pinned: counters of the run in flight
     rd_packet *h_recs_pin = nullptr; // pinned: records of the run in flight (rec_cap entries)
@@ -298,6 +300,8 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     b->rec_pin_cap = b->rec_cap;
     HIPCHK(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b->kdone, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     b->dev_ready = true;
     return RD_OK;
 }
@@ -309,6 +313,8 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_matches); hipFree(b->d_recs);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
+        if (b->kdone) hipEventDestroy(b->kdone);
+        if (b->copy_stream) hipStreamDestroy(b->copy_stream);
         for (auto &e : b->evs) if (e) hipEventDestroy(e);
     }
     delete b;
@@ -346,10 +352,16 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     if (b->timing) hipEventRecord(b->ev[4], st);
     // results come back with the run: counters plus as many records as the last run produced
     // (+25 %); rd_batch_results fetches the remainder if this run produced more.
-    hipMemcpyAsync(b->h_cnt_pin, b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    // The copies run on their own stream so that another batch's kernels queued on `st` need
+    // not wait for them.
+    hipEventRecord(b->kdone, st);
+    hipStreamWaitEvent(b->copy_stream, b->kdone, 0);
+    hipMemcpyAsync(b->h_cnt_pin, b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
     const uint32_t spec = std::min(b->rec_cap, b->spec_recs);
-    if (spec) hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st);
-    hipEventRecord(b->done, st);
+    if (spec)
+        hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
+                       b->copy_stream);
+    hipEventRecord(b->done, b->copy_stream);
 }
 
 extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
@@ -359,6 +371,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     b->stream = st;
     const rd_layout lay = batch_layout(b);
+    if (b->ran) HIPCHK(hipStreamWaitEvent(st, b->done, 0));  // the previous run's readback of d_cnt / d_recs
     HIPCHK(hipMemsetAsync(b->d_cnt, 0, RD_CNT_SLOTS * sizeof(uint32_t), st));
     if (b->timing) {
         if (b->evs.size() < 5 * (b->ev_runs + 1)) {

@@ -256,7 +256,18 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
             const long t0 = (long)(off - s * bytes_per_stream) * RD_GROUP;
             v.base = lay.iq + (size_t)s * lay.stream_stride;
             const long left = (long)lay.n_samples - t0;
-            ((uint8_t *)lay.bits)[off] = (uint8_t)rd_exact_run(v, t0, left < RD_GROUP ? (int)left : RD_GROUP);
+            const int count = left < RD_GROUP ? (int)left : RD_GROUP;
+            // samples t0-10 .. t0+9 = 40 bytes at a 4-byte aligned address: ten independent loads.
+            // Dwords wholly before the first readable sample are not touched (no history there).
+            const uint8_t *p = v.base + 2 * (t0 - 10);
+            uint32_t dw[10];
+#pragma unroll
+            for (int d = 0; d < 10; d++) {
+                const long n_hi = t0 - 10 + 2 * d + 1;  // last sample in this dword
+                dw[d] = (n_hi >= v.valid_from && t0 - 10 + 2 * d < (long)lay.n_samples + 8)
+                            ? *(const uint32_t *)(p + 4 * d) : 0u;
+            }
+            ((uint8_t *)lay.bits)[off] = (uint8_t)rd_exact_group_dw(dw, t0, count, v.valid_from);
         }
     }
 }
@@ -332,11 +343,20 @@ __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bit
 #pragma unroll
             for (int o = 0; o < RD_SEARCH_OUT; o++) m[o] = 0xFFFFFFFFu;
             if constexpr (S_ > 0) {
-                constexpr int NW = RD_SEARCH_OUT + ((P_ - 1) * S_ + 31) / 32 + 1;
-                const long w0 = p0 >> 5;
+                constexpr int NW = ((RD_SEARCH_OUT + ((P_ - 1) * S_ + 31) / 32 + 1 + 3) / 4) * 4;
+                const long w0 = p0 >> 5;  // multiple of 4 words: 16-byte aligned when the stream's words are
                 uint32_t r[NW];
+                if (w0 >= 0 && w0 + NW <= nwords && (((size_t)(w + w0)) & 15) == 0) {
+                    // interior: NW/4 coalesced 16-byte loads (lane i reads bytes 16i.. of the wave's span)
 #pragma unroll
-                for (int j = 0; j < NW; j++) r[j] = rd_word_at(w, nwords, w0 + j);
+                    for (int j = 0; j < NW / 4; j++) {
+                        const uint4 v4 = *(const uint4 *)(w + w0 + 4 * j);
+                        r[4 * j] = v4.x; r[4 * j + 1] = v4.y; r[4 * j + 2] = v4.z; r[4 * j + 3] = v4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NW; j++) r[j] = rd_word_at(w, nwords, w0 + j);
+                }
 #pragma unroll
                 for (int k = 0; k < P_; k++) {
                     const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
@@ -508,61 +528,88 @@ __device__ __forceinline__ void rd_rssi_record(const View &v, long origin, const
 // uint8 input: the window means are evaluated in fp32 (|f|^2 to ~1e-6 relative, 4e-6 dB; the
 // tolerance on RSSI/SNR is 1e-3 dB).  Each lane takes a contiguous slice of the window so the
 // nine-sample FIR history slides through registers (15 conversions for 7 outputs).
+// One pass of the RSSI window for a wave: lane handles PER outputs from window index j0.
+// PH0 = phase (index mod 4) of the first sample it reads - wave-uniform because every lane's
+// start differs by 8 samples - so the Fs/4 rotation and the dword/half selection are static.
+template <int PH0, int PER>
+__device__ __forceinline__ void rd_rssi_pass(const rd_stream_view &v, long n0, long j0, long q, long pe,
+                                             float &noise, float &sig) {
+    const float c[9] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4,
+                        (float)RD_C3, (float)RD_C2, (float)RD_C1, (float)RD_C0};
+    constexpr int ODD = PH0 & 1;
+    constexpr int ND = (PER + 8 + ODD + 1) / 2;  // aligned dwords (two samples each) covering PER+8 samples
+    const long ne = n0 - ODD;
+    uint32_t dw[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        const long n = ne + 2 * d;
+        dw[d] = (n + 1 >= v.valid_from && n < v.n + 8) ? *(const uint32_t *)(v.base + 2 * n) : 0u;
+    }
+    float yr[PER + 8], yi[PER + 8];
+#pragma unroll
+    for (int k = 0; k < PER + 8; k++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int i = k + ODD;
+        const uint32_t h = dw[i >> 1] >> (16 * (i & 1));
+        float a = ((float)(h & 0xFF) - 127.4f) * (1.0f / 127.6f);
+        float b = ((float)((h >> 8) & 0xFF) - 127.4f) * (1.0f / 127.6f);
+        if (n0 + k < v.valid_from) { a = 0.0f; b = 0.0f; }
+        const int ph = (PH0 + k) & 3;  // static
+        yr[k] = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
+        yi[k] = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
+    }
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        float fr = 0.0f, fi = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 9; m++) {  // f[t] = sum_m c_m y[t-9+m]; y[t-9+m] is window index r+m
+            fr = __builtin_fmaf(c[m], yr[r + m], fr);
+            fi = __builtin_fmaf(c[m], yi[r + m], fi);
+        }
+        const float pw = fr * fr + fi * fi;
+        const long j = j0 + r;
+        if (j < pe) { if (j < q) noise += pw; else sig += pw; }
+    }
+}
+
+__device__ __forceinline__ float rd_wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+
+// uint8 input: the window means are evaluated in fp32 (|f|^2 to ~1e-6 relative; 10*log10 through
+// v_log_f32, ~3e-6 dB; the tolerance on RSSI/SNR is 1e-3 dB).
 __device__ __forceinline__ void rd_rssi_record_u8(const rd_stream_view &v, long origin, const rd_devcfg &cfg,
                                                   rd_packet *o, int lane) {
     const long q = o->index;
     const long ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
     const long pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
-    const long per = (pe - ns + 63) / 64;  // outputs per lane
-    const long j0 = ns + per * lane;
-    const long j1 = j0 + per < pe ? j0 + per : pe;
-    const float c[9] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4,
-                        (float)RD_C3, (float)RD_C2, (float)RD_C1, (float)RD_C0};
-    float wr[9], wi[9];  // y[t-9 .. t-1] for the next output t
+    constexpr int PER = 8;  // outputs per lane per pass: 64 * 8 = 512 window positions per pass
     float noise = 0.0f, sig = 0.0f;
-    if (j0 < j1) {
-        const long t0 = origin + j0 - 1;  // first output index
-#pragma unroll
-        for (int m = 0; m < 9; m++) {
-            const long n = t0 - 9 + m;
-            float a = 0.0f, b = 0.0f;
-            if (n >= v.valid_from) {
-                a = ((float)v.base[2 * n] - 127.4f) * (1.0f / 127.6f);
-                b = ((float)v.base[2 * n + 1] - 127.4f) * (1.0f / 127.6f);
+    for (long jb = ns; jb < pe; jb += 64 * PER) {
+        const long j0 = jb + (long)PER * lane;
+        // outputs j0 .. j0+PER-1 are f[t], t = origin + j - 1, each using y[t-9 .. t-1]:
+        // samples n0 .. n0 + PER + 7 with n0 = origin + j0 - 10
+        const long n0 = origin + j0 - 10;
+        const int ph0 = __builtin_amdgcn_readfirstlane((int)(n0 & 3));
+        if (j0 < pe) {
+            switch (ph0) {
+                case 0: rd_rssi_pass<0, PER>(v, n0, j0, q, pe, noise, sig); break;
+                case 1: rd_rssi_pass<1, PER>(v, n0, j0, q, pe, noise, sig); break;
+                case 2: rd_rssi_pass<2, PER>(v, n0, j0, q, pe, noise, sig); break;
+                default: rd_rssi_pass<3, PER>(v, n0, j0, q, pe, noise, sig); break;
             }
-            const int ph = (int)(n & 3);
-            wr[m] = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
-            wi[m] = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
-        }
-        for (long j = j0; j < j1; j++) {
-            float fr = 0.0f, fi = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 9; m++) {
-                fr = __builtin_fmaf(c[m], wr[m], fr);
-                fi = __builtin_fmaf(c[m], wi[m], fi);
-            }
-            const float pw = fr * fr + fi * fi;
-            if (j < q) noise += pw; else sig += pw;
-            // slide: the next output also uses the sample at index t-1+1 = origin + j - 1
-            const long n = origin + j - 1;
-#pragma unroll
-            for (int m = 0; m < 8; m++) { wr[m] = wr[m + 1]; wi[m] = wi[m + 1]; }
-            float a = 0.0f, b = 0.0f;
-            if (n >= v.valid_from) {
-                a = ((float)v.base[2 * n] - 127.4f) * (1.0f / 127.6f);
-                b = ((float)v.base[2 * n + 1] - 127.4f) * (1.0f / 127.6f);
-            }
-            const int ph = (int)(n & 3);
-            wr[8] = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
-            wi[8] = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
         }
     }
-    const double noise_d = rd_wave_sum((double)noise), sig_d = rd_wave_sum((double)sig);
+    noise = rd_wave_sum_f32(noise);
+    sig = rd_wave_sum_f32(sig);
     if (lane == 0) {
-        const double noise_power = (q > ns) ? noise_d / (double)(q - ns) : 1e-9;
-        const double signal_power = (pe > q) ? sig_d / (double)(pe - q) : __builtin_nan("");
-        o->rssi = signal_power > 0 ? 10.0 * log10(signal_power) : -120.0;
-        o->snr = noise_power > 0 ? 10.0 * log10(signal_power / noise_power) : 50.0;
+        const float noise_power = (q > ns) ? noise / (float)(q - ns) : 1e-9f;
+        const float signal_power = (pe > q) ? sig / (float)(pe - q) : __builtin_nanf("");
+        // 10*log10(x) = 3.0102999566 * log2(x)
+        o->rssi = signal_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power)) : -120.0;
+        o->snr = noise_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power / noise_power)) : 50.0;
     }
 }
 

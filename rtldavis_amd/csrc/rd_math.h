@@ -373,6 +373,35 @@ RD_HD rd_i2 rd_f_int(const rd_stream_view &v, long t) {
     return rd_fir_int(y);
 }
 
+// Exact bits of the 8-sample group starting at t0 (t0 % 8 == 0) from ten preloaded dwords that
+// hold samples t0-10 .. t0+9 (dword d = samples t0-10+2d, t0-9+2d as I,Q,I,Q bytes).  Used by
+// k_fixup so that all of a group's input is fetched with independent, aligned 4-byte loads.
+// `first_valid`: samples with index < first_valid (zero history) read as y = 0.
+RD_HD uint32_t rd_exact_group_dw(const uint32_t *dw, long t0, int count, long first_valid) {
+    rd_i2 y[9];
+    auto sample = [&](int i) {  // i = index into the 20-sample window
+        const long n = t0 - 10 + i;
+        rd_i2 z = {0, 0};
+        if (n < first_valid) return z;
+        const uint32_t d = dw[i >> 1] >> (16 * (i & 1));
+        return rd_rot_int((int)(d & 0xFF), (int)((d >> 8) & 0xFF), (int)(n & 3));
+    };
+#pragma unroll
+    for (int m = 0; m < 9; m++) y[m] = sample(m);
+    rd_i2 prev = rd_fir_int(y);  // f[t0-1]
+    uint32_t word = 0;
+#pragma unroll
+    for (int r = 0; r < RD_GROUP; r++) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) y[m] = y[m + 1];
+        y[8] = sample(r + 9);  // sample t0+r-1
+        const rd_i2 cur = rd_fir_int(y);  // f[t0+r]
+        if (r < count) word |= rd_exact_bit(prev, cur) << r;
+        prev = cur;
+    }
+    return word;
+}
+
 // Exact bits of samples [t0, t0+count), count <= 32, as a packed word (bit r = sample t0+r).
 RD_HD uint32_t rd_exact_run(const rd_stream_view &v, long t0, int count) {
     rd_i2 y[9];

@@ -36,6 +36,24 @@ uint8_t hh_exact_group(const uint8_t *iq, long n, long t0) {
     return (uint8_t)rd_exact_run(v, t0, (int)(n - t0 < RD_GROUP ? n - t0 : RD_GROUP));
 }
 
+// the same group through the dword-window form k_fixup uses
+uint8_t hh_exact_group_dw(const uint8_t *iq, long n, long t0) {
+    uint32_t dw[10];
+    for (int d = 0; d < 10; d++) {
+        const long s0 = t0 - 10 + 2 * d;
+        dw[d] = 0;
+        if (s0 + 1 >= 0 && s0 < n + 8) {
+            uint8_t b[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4; k++) {
+                const long idx = 2 * s0 + k;
+                if (idx >= 0 && idx < 2 * n) b[k] = iq[idx];
+            }
+            memcpy(&dw[d], b, 4);
+        }
+    }
+    return (uint8_t)rd_exact_group_dw(dw, t0, (int)(n - t0 < RD_GROUP ? n - t0 : RD_GROUP), 0);
+}
+
 void hh_exact_stream(const uint8_t *iq, long n, uint32_t *words) {
     rd_stream_view v = {iq, 0, n};
     for (long t0 = 0; t0 < n; t0 += RD_RUN) {

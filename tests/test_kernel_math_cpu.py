@@ -28,6 +28,8 @@ def hh():
     L.hh_exact_stream.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
     L.hh_exact_group.restype = C.c_uint8
     L.hh_exact_group.argtypes = [C.c_void_p, C.c_long, C.c_long]
+    L.hh_exact_group_dw.restype = C.c_uint8
+    L.hh_exact_group_dw.argtypes = [C.c_void_p, C.c_long, C.c_long]
     L.hh_f64_stream.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     L.hh_threshold.restype = C.c_float
     L.hh_threshold.argtypes = [C.c_float]
@@ -77,6 +79,22 @@ def test_exact_path_equals_oracle_and_guard_covers_fast_path(hh, name, raw):
         assert hh.hh_exact_group(np.ascontiguousarray(raw).ctypes.data, n, int(gi) * 8) == rb[gi]
     if name in ("synthetic0", "uniform"):
         assert nf / gflag.size < 0.02
+
+
+def test_fixup_dword_window_form_equals_run_form(hh):
+    rng = np.random.default_rng(17)
+    raw = rng.integers(0, 256, size=2 * 4096, dtype=np.uint8)
+    f, d, bits = O.demod_stream_oneshot(raw)
+    ref = O.pack_bits_le(bits)
+    for g in list(range(0, 8)) + list(rng.integers(0, 512, size=100)) + [511]:
+        assert hh.hh_exact_group_dw(raw.ctypes.data, 4096, int(g) * 8) == ref[int(g)], g
+    # ragged end: 1000 samples, last group holds 8 valid samples, a 996-sample stream holds 4
+    for n in (1000, 996):
+        f, d, bits = O.demod_stream_oneshot(raw[: 2 * n])
+        want = np.zeros(1024, np.uint8); want[:n] = bits
+        ref = O.pack_bits_le(want)
+        g = (n - 1) // 8
+        assert hh.hh_exact_group_dw(raw.ctypes.data, n, g * 8) == ref[g]
 
 
 def test_ragged_tail_exact(hh):
