@@ -179,6 +179,18 @@ def main():
         if not ok:
             raise SystemExit("bench.py: GPU output differs from the reference fixtures - result invalid")
 
+    # HBM traffic of the dominant kernel: measured with PMC counters in a separate rocprofv3 run
+    # (tools/pmc_traffic.sh) and committed under profiles/; valid for the default workload only
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            tj = json.load(fh)
+        w = tj["workload"]
+        if (w["streams"], w["blocks"], w["block_size"]) == (n_streams, n_blocks, cfg.block_size):
+            traffic = int(tj["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         samples_step = n_streams * n_samples
         ms_step = elapsed / args.steps * 1e3
@@ -196,7 +208,7 @@ def main():
                                    f"{in_bytes / 1e9:.2f} GB resident in HBM), 14 samples/symbol, 19.2 kbit/s",
                        "streams_per_gpu": n_streams, "samples_per_stream": n_samples, "parallelism": f"streams/{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_demod_bits", "kernel_ms": round(dm, 4),
                          "algorithmic_bytes_per_launch": samples_step * 2},
             "kernels_ms": {k[:-3]: round(float(tm[k]), 4) for k in ("demod_ms", "fixup_ms", "search_ms", "slice_ms",
