@@ -226,6 +226,7 @@ struct rd_batch {
     uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
     rd_match *d_matches = nullptr;
     rd_packet *d_recs = nullptr;
+    rd_dedupe_ws ws = {};
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> evs;  // 5 events per timed run, read back in rd_batch_get_timing
@@ -279,6 +280,25 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
     return RD_OK;
 }
 
+static uint32_t pow2_at_least(uint64_t v) {
+    uint32_t p = 1024;
+    while (p < v && p < (1u << 31)) p <<= 1;
+    return p;
+}
+
+static void free_dedupe_ws(rd_dedupe_ws &ws) {
+    hipFree(ws.table); hipFree(ws.slot_of); hipFree(ws.final_recs);
+    ws = rd_dedupe_ws{};
+}
+
+static int alloc_dedupe_ws(rd_dedupe_ws &ws, uint32_t rec_cap) {
+    ws.slots = pow2_at_least(2ull * rec_cap);
+    HIPCHK(hipMalloc(&ws.table, (size_t)ws.slots * 16));
+    HIPCHK(hipMalloc(&ws.slot_of, (size_t)rec_cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&ws.final_recs, (size_t)rec_cap * sizeof(rd_packet)));
+    return RD_OK;
+}
+
 static int batch_alloc(rd_batch *b) {
     if (b->dev_ready) return RD_OK;
     int rc = ensure_device();
@@ -287,7 +307,8 @@ static int batch_alloc(rd_batch *b) {
     b->iq_bytes = (size_t)b->n_streams * b->n_samples * 2;
     // guard-band list entries are 8-sample groups (4 per run); ~0.5 % of them on noise
     b->fix_cap = (uint32_t)std::min<uint64_t>(4 * runs, std::max<uint64_t>(4096, runs / 4));
-    b->match_cap = (uint32_t)std::min<uint64_t>((uint64_t)b->n_streams * (16 + 4ull * b->n_blocks), 1u << 26);
+    // ~16 raw matches per 33-block stream on noise + one burst; the lists grow on overflow
+    b->match_cap = (uint32_t)std::min<uint64_t>((uint64_t)b->n_streams * (8 + 1ull * b->n_blocks) + 1024, 1u << 26);
     b->rec_cap = 2 * b->match_cap;
     HIPCHK(hipMalloc(&b->d_iq, b->iq_bytes + RD_INPUT_PAD));
     HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));
@@ -296,6 +317,7 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMalloc(&b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+    { int rc2 = alloc_dedupe_ws(b->ws, b->rec_cap); if (rc2) return rc2; }
     HIPCHK(hipHostMalloc((void **)&b->h_cnt_pin, RD_CNT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     b->rec_pin_cap = b->rec_cap;
@@ -311,6 +333,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
     if (b->dev_ready && g_hip_pid == getpid()) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs);
+        free_dedupe_ws(b->ws);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
@@ -348,7 +371,7 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
                      b->dc, b->d_matches, b->match_cap, b->d_cnt, st);
     if (b->timing) hipEventRecord(b->ev[3], st);
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
-                    b->d_recs, b->rec_cap, b->d_cnt, st);
+                    b->d_recs, b->rec_cap, b->ws, b->d_cnt, st);
     if (b->timing) hipEventRecord(b->ev[4], st);
     // results come back with the run: counters plus as many records as the last run produced
     // (+25 %); rd_batch_results fetches the remainder if this run produced more.
@@ -359,7 +382,7 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     hipMemcpyAsync(b->h_cnt_pin, b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
     const uint32_t spec = std::min(b->rec_cap, b->spec_recs);
     if (spec)
-        hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
+        hipMemcpyAsync(b->h_recs_pin, b->ws.final_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
                        b->copy_stream);
     hipEventRecord(b->done, b->copy_stream);
 }
@@ -417,10 +440,12 @@ static int batch_finish(rd_batch *b) {
         }
         if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
             hipFree(b->d_matches); hipFree(b->d_recs); hipHostFree(b->h_recs_pin);
-            b->match_cap = b->h_cnt[RD_CNT_MATCH] + 1024;
+            free_dedupe_ws(b->ws);
+            b->match_cap = b->h_cnt[RD_CNT_MATCH] + b->h_cnt[RD_CNT_MATCH] / 4 + 1024;
             b->rec_cap = 2 * b->match_cap;
             HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
             HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+            { int rc2 = alloc_dedupe_ws(b->ws, b->rec_cap); if (rc2) return rc2; }
             HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
             b->rec_pin_cap = b->rec_cap;
             redo_search = true;
@@ -429,7 +454,7 @@ static int batch_finish(rd_batch *b) {
             b->last_match = b->h_cnt[RD_CNT_MATCH];
             return RD_OK;
         }
-        const uint32_t zero[2] = {0, 0};
+        const uint32_t zero[3] = {0, 0, 0};  // matches, raw records, final records
         HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
         batch_search_slice(b, st);
     }
@@ -442,10 +467,11 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     int rc = batch_finish(b);
     if (rc) return rc;
     const double t1 = now_ms();
-    const uint32_t nrec = std::min(b->h_cnt[RD_CNT_REC], b->rec_cap);
+    const uint32_t nrec = std::min(b->h_cnt[RD_CNT_FINAL], b->rec_cap);  // after the on-device dedupe
     const uint32_t have = std::min(b->rec_cap, b->spec_recs);
     if (nrec > have) {  // more records than were copied back with the run: fetch the rest
-        rc = copy_d2h(b->h_recs_pin + have, b->d_recs + have, (size_t)(nrec - have) * sizeof(rd_packet), b->stream);
+        rc = copy_d2h(b->h_recs_pin + have, b->ws.final_recs + have, (size_t)(nrec - have) * sizeof(rd_packet),
+                      b->stream);
         if (rc) return rc;
     }
     b->spec_recs = std::max<uint32_t>(1024, nrec + nrec / 4);
@@ -551,6 +577,7 @@ struct rd_demod {
     int cur_win = 0;
     rd_match *d_matches = nullptr;
     rd_packet *d_recs = nullptr;
+    rd_dedupe_ws ws = {};
     double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
     uint8_t *h_in = nullptr;        // pinned staging of one input block
     uint32_t *h_cnt = nullptr;      // pinned
@@ -595,6 +622,7 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
     HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(rd_packet)));
+    { int rc2 = alloc_dedupe_ws(h->ws, h->rec_cap); if (rc2) return rc2; }
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&h->h_in, 16 * B, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
@@ -609,6 +637,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_stage); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_recs); hipFree(h->d_tmp);
+        free_dedupe_ws(h->ws);
         hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs);
     }
     delete h;
@@ -720,21 +749,21 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
     rd_launch_search(h->d_win[nw], 0, 1, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
     if (!h->cplx_mode)
         rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], 0, (long)L, h->dc, h->d_matches, h->match_cap, 0, 0,
-                        (int)seen_before, h->d_recs, h->rec_cap, h->d_cnt, st);
+                        (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
     else
         rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
-                             (int)seen_before, h->d_recs, h->rec_cap, h->d_cnt, st);
+                             (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
     HIPCHK(hipGetLastError());
     // counters and the first records come back with the block; polling wait (see wait_stream)
     const uint32_t spec = std::min<uint32_t>(h->rec_cap, 32);
     HIPCHK(hipMemcpyAsync(h->h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h->h_recs, h->ws.final_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
     rc = wait_stream(st);
     if (rc) return rc;
     h->seen = seen_before + 1;
-    const uint32_t nrec = std::min(h->h_cnt[RD_CNT_REC], h->rec_cap);
+    const uint32_t nrec = std::min(h->h_cnt[RD_CNT_FINAL], h->rec_cap);
     if (nrec > spec) {
-        rc = copy_d2h(h->h_recs + spec, h->d_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
+        rc = copy_d2h(h->h_recs + spec, h->ws.final_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
         if (rc) return rc;
     }
     std::vector<rd_packet> recs;

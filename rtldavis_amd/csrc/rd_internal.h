@@ -6,7 +6,7 @@
 #include "../../include/rtldavis_hip.h"
 
 // counters[] slots (device uint32)
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_SLOTS = 8 };
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_FINAL = 3, RD_CNT_SLOTS = 8 };
 
 // Geometry of the fused demod kernel
 #define RD_TILE_SAMPLES 2048  // 64 lanes x 32 samples: one wave iteration
@@ -36,6 +36,15 @@ struct rd_match {
     int32_t pos;  // bit-array coordinate of the first preamble sample
 };
 
+// Workspace of the on-device per-call dedupe (py:203-205: first occurrence of a byte string
+// wins inside one call): an open-addressing table keyed by (stream, call, data).
+struct rd_dedupe_ws {
+    uint64_t *table;     // 2 * slots u64: [2s] = owner record (all ones = empty), [2s+1] = min order key
+    uint32_t slots;      // power of two, >= 2 * rec_cap
+    uint32_t *slot_of;   // rec_cap entries: table slot of each raw record
+    rd_packet *final_recs;  // rec_cap entries: surviving records, compacted (RD_CNT_FINAL of them)
+};
+
 // --- launches (all asynchronous on `st`) ---
 void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
@@ -49,9 +58,11 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 // Slice + RSSI/SNR.  batch_mode = 1: position = absolute sample, calls derived from it
 // (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
 // lay.iq points at the newest block's first sample.
+// Raw records go to `recs` (RD_CNT_REC), per-call duplicates are dropped on the device and the
+// survivors, with RSSI/SNR filled in, land compacted in ws.final_recs (RD_CNT_FINAL).
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, uint32_t rec_cap, uint32_t *counters, hipStream_t st);
+                     rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st);
 // d[t0 .. t0+n) of stream `stream` in float64
 void rd_launch_disc(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
 // f[t0 .. t0+n) (interleaved re,im) of stream `stream` in float64
@@ -71,7 +82,7 @@ void rd_launch_cplx_disc(const rd_cplx_layout &lay, long t0, long n, double *out
 void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
                           const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t rec_cap,
-                          uint32_t *counters, hipStream_t st);
+                          const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st);
 void rd_launch_lut(const uint8_t *in, double *out, size_t n_cplx, hipStream_t st);
 
 // stage kernels on device arrays (float64)

@@ -495,6 +495,91 @@ __global__ __launch_bounds__(64) void k_slice(const uint32_t *bits, size_t bits_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-call dedupe on the device (py:203-205).  Among the records of one call that carry the
+// same bytes the reference keeps the first in its search order, i.e. the smallest
+// (index % S, index).  k_dedupe_insert finds/creates the table slot of (stream, call, data) and
+// atomically lowers its order key; k_dedupe_select keeps the record whose key is the slot's
+// minimum and compacts the survivors.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rd_rec_hash(const rd_packet *r) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (((uint64_t)(uint32_t)r->stream << 32) | (uint32_t)r->call);
+    const uint32_t *d = (const uint32_t *)r->data;
+#pragma unroll
+    for (int i = 0; i < RD_MAX_PKT_BYTES / 4; i++) {
+        h = (h ^ d[i]) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    return h;
+}
+
+__device__ __forceinline__ bool rd_rec_same(const rd_packet *a, const rd_packet *b) {
+    if (a->stream != b->stream || a->call != b->call) return false;
+    const uint32_t *x = (const uint32_t *)a->data, *y = (const uint32_t *)b->data;
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < RD_MAX_PKT_BYTES / 4; i++) same &= x[i] == y[i];
+    return same;
+}
+
+__device__ __forceinline__ uint64_t rd_order_key(const rd_packet *r, int S) {
+    return ((uint64_t)(uint32_t)(r->index % S) << 32) | (uint32_t)r->index;
+}
+
+__global__ __launch_bounds__(256) void k_dedupe_insert(const rd_packet *recs, uint32_t rec_cap, rd_dedupe_ws ws, int S,
+                                                       const uint32_t *counters) {
+    uint32_t count = counters[RD_CNT_REC];
+    if (count > rec_cap) count = rec_cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const rd_packet *r = &recs[i];
+    const uint64_t key = rd_order_key(r, S);
+    unsigned long long *tab = (unsigned long long *)ws.table;
+    uint32_t slot = (uint32_t)rd_rec_hash(r) & (ws.slots - 1);
+    for (uint32_t probe = 0; probe < ws.slots; probe++) {
+        const unsigned long long owner = atomicCAS(&tab[2 * (size_t)slot], ~0ull, (unsigned long long)i);
+        if (owner == ~0ull || rd_rec_same(&recs[owner], r)) {
+            atomicMin(&tab[2 * (size_t)slot + 1], (unsigned long long)key);
+            ws.slot_of[i] = slot;
+            return;
+        }
+        slot = (slot + 1) & (ws.slots - 1);
+    }
+    ws.slot_of[i] = 0xFFFFFFFFu;  // table full: cannot happen (slots >= 2 * rec_cap); kept as survivor
+}
+
+__global__ __launch_bounds__(256) void k_dedupe_select(const rd_packet *recs, uint32_t rec_cap, rd_dedupe_ws ws, int S,
+                                                       uint32_t *counters) {
+    uint32_t count = counters[RD_CNT_REC];
+    if (count > rec_cap) count = rec_cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool keep = false;
+    if (i < count) {
+        const uint32_t slot = ws.slot_of[i];
+        keep = slot == 0xFFFFFFFFu || ws.table[2 * (size_t)slot + 1] == rd_order_key(&recs[i], S);
+    }
+    const uint64_t km = __ballot(keep);
+    if (!km) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[RD_CNT_FINAL], (uint32_t)__popcll(km));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (!keep) return;
+    const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
+    const uint4 *src = (const uint4 *)&recs[i];
+    uint4 *out = (uint4 *)&ws.final_recs[dst];
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(rd_packet) / 16); j++) out[j] = src[j];
+}
+
+static void rd_launch_dedupe(const rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, int S, uint32_t *counters,
+                             hipStream_t st) {
+    hipMemsetAsync(ws.table, 0xFF, (size_t)ws.slots * 16, st);
+    const uint32_t wgs = (rec_cap + 255) / 256;
+    hipLaunchKernelGGL(k_dedupe_insert, dim3(wgs), dim3(256), 0, st, recs, rec_cap, ws, S, counters);
+    hipLaunchKernelGGL(k_dedupe_select, dim3(wgs), dim3(256), 0, st, recs, rec_cap, ws, S, counters);
+}
+
 __device__ __forceinline__ double rd_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -616,7 +701,7 @@ __device__ __forceinline__ void rd_rssi_record_u8(const rd_stream_view &v, long 
 __global__ __launch_bounds__(256) void k_rssi(rd_layout lay, rd_devcfg cfg, int batch_mode, rd_packet *recs,
                                               uint32_t rec_cap, const uint32_t *counters) {
     const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_REC];
+    uint32_t count = counters[RD_CNT_FINAL];
     if (count > rec_cap) count = rec_cap;
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
@@ -632,7 +717,7 @@ __global__ __launch_bounds__(256) void k_rssi(rd_layout lay, rd_devcfg cfg, int 
 __global__ __launch_bounds__(256) void k_cplx_rssi(rd_cplx_view v, rd_devcfg cfg, rd_packet *recs, uint32_t rec_cap,
                                                    const uint32_t *counters) {
     const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_REC];
+    uint32_t count = counters[RD_CNT_FINAL];
     if (count > rec_cap) count = rec_cap;
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw)
@@ -647,14 +732,15 @@ static uint32_t rd_rssi_grid(uint32_t rec_cap) {
 
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, uint32_t rec_cap, uint32_t *counters, hipStream_t st) {
+                     rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st) {
     uint32_t wgs = (match_cap + 63) / 64;  // 64-thread workgroups: one wave each, spread over the CUs
     if (wgs > 4096) wgs = 4096;
     if (wgs == 0) wgs = 1;
     hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(64), 0, st, bits, bits_stride, (n_bits + 31) / 32, cfg, matches,
                        match_cap, batch_mode, n_calls, call, recs, rec_cap, counters);
-    hipLaunchKernelGGL(k_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, lay, cfg, batch_mode, recs, rec_cap,
-                       counters);
+    rd_launch_dedupe(recs, rec_cap, ws, cfg.S, counters, st);
+    hipLaunchKernelGGL(k_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, lay, cfg, batch_mode, ws.final_recs,
+                       rec_cap, counters);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -766,14 +852,16 @@ void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double 
 
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
                           const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t rec_cap,
-                          uint32_t *counters, hipStream_t st) {
+                          const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st) {
     uint32_t wgs = (match_cap + 63) / 64;
     if (wgs > 4096) wgs = 4096;
     if (wgs == 0) wgs = 1;
     rd_cplx_view v = {lay.x, lay.valid_from, lay.n};
     hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(64), 0, st, bits, (size_t)0, (n_bits + 31) / 32, cfg, matches,
                        match_cap, 0, 0, call, recs, rec_cap, counters);
-    hipLaunchKernelGGL(k_cplx_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, v, cfg, recs, rec_cap, counters);
+    rd_launch_dedupe(recs, rec_cap, ws, cfg.S, counters, st);
+    hipLaunchKernelGGL(k_cplx_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, v, cfg, ws.final_recs, rec_cap,
+                       counters);
 }
 
 // ------------------------------------------------------------------------------------------
