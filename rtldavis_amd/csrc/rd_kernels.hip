@@ -318,7 +318,7 @@ __device__ __forceinline__ void rd_flush_matches(const rd_match *pend, uint32_t 
 
 // S_ > 0: compile-time symbol length / preamble length (register funnel with constant
 // shifts); S_ == 0: run-time cfg.S / cfg.P (words fetched per tap).
-template <int S_, int P_>
+template <int S_, int P_, uint64_t PRE_>
 __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
                                                 long base, long groups_per_stream, long p_lo, long p_hi,
                                                 rd_devcfg cfg, rd_match *matches, uint32_t match_cap,
@@ -327,17 +327,18 @@ __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bit
     const int lane = threadIdx.x & 63;
     rd_match *pend = pend_all[threadIdx.x >> 6];
     uint32_t npend = 0;  // wave-uniform
-    const uint64_t total = (uint64_t)n_streams * groups_per_stream;  // lane-groups of 128 positions
-    const uint64_t nwave_groups = (total + 63) / 64;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    for (uint64_t wg = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wg < nwave_groups; wg += nwaves) {
-        const uint64_t g = wg * 64 + lane;
+    // a wave covers 64 consecutive lane-groups (128 positions each) of ONE stream, so the
+    // stream / group split is scalar arithmetic
+    const uint32_t wgps = (uint32_t)((groups_per_stream + 63) / 64);  // wave-groups per stream
+    const uint32_t nwave_groups = (uint32_t)n_streams * wgps;
+    const uint32_t nwaves = gridDim.x * 4;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    for (uint32_t wg = wave0; wg < nwave_groups; wg += nwaves) {
+        const uint32_t s = wg / wgps;
+        const long gi = (long)(wg - s * wgps) * 64 + lane;
         uint32_t m[RD_SEARCH_OUT] = {0, 0, 0, 0};
-        uint32_t s = 0;
         long p0 = 0;
-        if (g < total) {
-            s = (uint32_t)(g / groups_per_stream);
-            const long gi = (long)(g - (uint64_t)s * groups_per_stream);
+        if (gi < groups_per_stream) {
             p0 = base + 32L * RD_SEARCH_OUT * gi;
             const uint32_t *w = bits + (size_t)s * bits_stride;
 #pragma unroll
@@ -357,15 +358,28 @@ __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bit
 #pragma unroll
                     for (int j = 0; j < NW; j++) r[j] = rd_word_at(w, nwords, w0 + j);
                 }
+                // compile-time preamble: all[o] = AND of the taps that must be 1, any[o] = OR of the
+                // taps that must be 0 (two at a time with v_or3_b32); match = all & ~any
+                uint32_t any[RD_SEARCH_OUT] = {0, 0, 0, 0};
+                uint32_t held[RD_SEARCH_OUT];
+                bool have_held = false;
 #pragma unroll
                 for (int k = 0; k < P_; k++) {
-                    const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
                     const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
+                    const bool one = (PRE_ >> k) & 1;
 #pragma unroll
                     for (int o = 0; o < RD_SEARCH_OUT; o++) {
                         const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[o + wj + 1], r[o + wj], sh) : r[o + wj];
-                        m[o] &= v ^ x;
+                        if (one) m[o] &= v;
+                        else if (have_held) any[o] = any[o] | held[o] | v;
+                        else held[o] = v;
                     }
+                    if (!one) have_held = !have_held;
+                }
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                    if (have_held) any[o] |= held[o];
+                    m[o] &= ~any[o];
                 }
             } else {
                 for (int k = 0; k < cfg.P; k++) {
@@ -406,7 +420,25 @@ __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bit
             }
         }
     }
-    if (npend) rd_flush_matches(pend, npend, matches, match_cap, counters, lane);
+    // End of kernel: the four waves' leftovers leave through ONE atomic (every wave flushing
+    // its own few entries made 8192 serialized atomics = 90 us of a 110 us kernel).
+    __shared__ uint32_t left[4];
+    if (lane == 0) left[threadIdx.x >> 6] = npend;
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 0) {
+        const uint32_t n0 = left[0], n1 = left[1], n2 = left[2], n3 = left[3];
+        const uint32_t tot = n0 + n1 + n2 + n3;
+        if (tot) {
+            uint32_t base_slot = 0;
+            if (lane == 0) base_slot = atomicAdd(&counters[RD_CNT_MATCH], tot);
+            base_slot = __builtin_amdgcn_readfirstlane(base_slot);
+            for (uint32_t i = lane; i < tot; i += 64) {
+                const uint32_t wv = i < n0 ? 0 : i < n0 + n1 ? 1 : i < n0 + n1 + n2 ? 2 : 3;
+                const uint32_t off = i - (wv == 0 ? 0 : wv == 1 ? n0 : wv == 2 ? n0 + n1 : n0 + n1 + n2);
+                if (base_slot + i < match_cap) matches[base_slot + i] = pend_all[wv][off];
+            }
+        }
+    }
 }
 
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
@@ -418,12 +450,20 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
     const long groups = (p_hi - base) / (32 * RD_SEARCH_OUT) + 1;
     const uint64_t total = (uint64_t)n_streams * groups;
     uint64_t wgs = (total + 255) / 256;
-    if (wgs > 256ull * 8) wgs = 256ull * 8;
-    if (cfg.S == 14 && cfg.P == 16)  // the Davis configuration (protocol.py:68-76)
-        hipLaunchKernelGGL((k_search<14, 16>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams,
-                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
+    static int cap = 0;
+    if (!cap) {
+        const char *e = getenv("RD_K2_WGS_PER_CU");  // tuning knob
+        cap = e ? atoi(e) : 8;
+        if (cap < 1 || cap > 64) cap = 8;
+    }
+    if (wgs > 256ull * cap) wgs = 256ull * cap;
+    // the Davis configuration (protocol.py:68-76): 14 samples/symbol, preamble 1100101110001001
+    // (bit m of the mask = symbol m -> 0x91D3)
+    if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
+        hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride,
+                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
     else
-        hipLaunchKernelGGL((k_search<0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams,
+        hipLaunchKernelGGL((k_search<0, 0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams,
                            nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
 }
 
@@ -437,19 +477,9 @@ __device__ __forceinline__ uint32_t rd_bit_at(const uint32_t *w, long nwords, lo
     return (rd_word_at(w, nwords, o >> 5) >> (o & 31)) & 1u;
 }
 
-// All lanes of the wave must call this (valid = this lane has a record to emit).
-__device__ __forceinline__ void rd_emit_record(bool valid, const uint32_t *w, long nwords, long pos,
-                                               const rd_devcfg &cfg, int stream, int call, long q, rd_packet *recs,
-                                               uint32_t rec_cap, uint32_t *counters, int lane) {
-    const uint64_t vm = __ballot(valid);
-    if (!vm) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[RD_CNT_REC], (uint32_t)__popcll(vm));
-    base = __builtin_amdgcn_readfirstlane(base);
-    const uint32_t slot =
-        base + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0));
-    if (!valid || slot >= rec_cap) return;
-    rd_packet *o = &recs[slot];
+// Writes one record (all fields except RSSI/SNR, which k_rssi fills for the survivors).
+__device__ __forceinline__ void rd_write_record(rd_packet *o, const uint32_t *w, long nwords, long pos,
+                                                const rd_devcfg &cfg, int stream, int call, long q) {
     for (int bi = 0; bi < RD_MAX_PKT_BYTES; bi++) {
         uint32_t byte = 0;
         if (bi < cfg.nbytes)
@@ -460,7 +490,7 @@ __device__ __forceinline__ void rd_emit_record(bool valid, const uint32_t *w, lo
         o->data[bi] = (uint8_t)byte;
     }
     o->stream = stream; o->call = call; o->index = (int32_t)q; o->nbytes = cfg.nbytes;
-    o->rssi = 0.0; o->snr = 0.0;  // filled by k_rssi
+    o->rssi = 0.0; o->snr = 0.0;
 }
 
 __global__ __launch_bounds__(64) void k_slice(const uint32_t *bits, size_t bits_stride, long nwords, rd_devcfg cfg,
@@ -478,19 +508,34 @@ __global__ __launch_bounds__(64) void k_slice(const uint32_t *bits, size_t bits_
         rd_match mt = {0, 0};
         if (have) mt = matches[i];
         const uint32_t *w = bits + (size_t)mt.stream * bits_stride;
+        // Which call(s) report this position (py:194, q <= B): in batch mode call b sees absolute
+        // positions w_b <= p <= w_b + B with w_b = (b+1)B - L, so p is reported by one call, or by
+        // two when it falls on a block boundary (q = B in call b, q = 0 in call b+1).
+        long b0 = call, b1 = -1, q0 = mt.pos, q1 = 0;
+        bool ok0 = have, ok1 = false;
         if (batch_mode) {
-            // call b reports absolute positions w_b <= p <= w_b + B, w_b = (b+1)B - L (py:194: q <= B)
-            const long pl = (long)mt.pos + cfg.L;
-            const long b_hi = pl / cfg.B - 1;  // floor: pl >= B because p >= B - L
-            const long b_lo = (pl % cfg.B == 0) ? b_hi - 1 : b_hi;
-            for (int j = 0; j < 2; j++) {
-                const long b = b_hi - j;
-                const bool ok = have && b >= b_lo && b >= 0 && b < n_calls;
-                const long q = (long)mt.pos - ((b + 1) * (long)cfg.B - cfg.L);
-                rd_emit_record(ok, w, nwords, mt.pos, cfg, mt.stream, (int)b, q, recs, rec_cap, counters, lane);
-            }
-        } else {
-            rd_emit_record(have, w, nwords, mt.pos, cfg, mt.stream, call, mt.pos, recs, rec_cap, counters, lane);
+            const long pl = (long)mt.pos + cfg.L;  // >= B because p >= B - L
+            b0 = pl / cfg.B - 1;
+            q0 = (long)mt.pos - ((b0 + 1) * (long)cfg.B - cfg.L);
+            ok0 = have && b0 >= 0 && b0 < n_calls;
+            b1 = b0 - 1;
+            q1 = q0 + cfg.B;
+            ok1 = have && (pl % cfg.B == 0) && b1 >= 0 && b1 < n_calls;
+        }
+        // one slot reservation per wave and round for both
+        const uint64_t m0 = __ballot(ok0), m1 = __ballot(ok1);
+        if (!(m0 | m1)) continue;
+        const uint32_t n0 = (uint32_t)__popcll(m0);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&counters[RD_CNT_REC], n0 + (uint32_t)__popcll(m1));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ok0) {
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
+            if (slot < rec_cap) rd_write_record(&recs[slot], w, nwords, mt.pos, cfg, mt.stream, (int)b0, q0);
+        }
+        if (ok1) {
+            const uint32_t slot = base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
+            if (slot < rec_cap) rd_write_record(&recs[slot], w, nwords, mt.pos, cfg, mt.stream, (int)b1, q1);
         }
     }
 }

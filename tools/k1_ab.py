@@ -1,12 +1,12 @@
-"""A/B timing of k_demod_bits variants under continuous load (diagnostic).
-Each variant is selected through an environment variable read at library load, so every
-variant runs in its own subprocess; all share one GPU box and are interleaved round-robin.
-usage: k1_ab.py 'NAME=ENV1=V1,ENV2=V2' ...   (NAME alone = defaults)"""
+"""A/B timing of kernel variants under continuous load (diagnostic).
+Each variant is selected through environment variables read at library load, so every variant
+runs in its own subprocess; all share one GPU box and are interleaved round-robin.
+usage: k1_ab.py [--key demod_ms] 'NAME=ENV1=V1,ENV2=V2' ...   (NAME alone = defaults)"""
 import json, os, subprocess, sys
 
 CHILD = r'''
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[0]))) if False else os.getcwd())
+sys.path.insert(0, os.getcwd())
 import numpy as np
 from rtldavis_amd import batch, dsp, synth
 cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 8192)
@@ -23,8 +23,12 @@ print(json.dumps(bd.timing()))
 '''
 
 def main():
+    args = sys.argv[1:]
+    key = "demod_ms"
+    if args and args[0] == "--key":
+        key = args[1]; args = args[2:]
     variants = []
-    for a in sys.argv[1:]:
+    for a in args:
         name, _, envs = a.partition("=")
         env = dict(kv.split("=", 1) for kv in envs.split(",") if kv) if envs else {}
         variants.append((name, env))
@@ -35,10 +39,10 @@ def main():
             out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True, cwd=os.getcwd())
             try:
                 t = json.loads(out.stdout.strip().splitlines()[-1])
-                res[name].append(t["demod_ms"])
+                res[name].append(t[key])
             except Exception:
                 print(name, "FAILED", out.stderr[-400:])
     for name, v in res.items():
-        print(f"{name:24s} demod_ms min {min(v):.4f}  med {sorted(v)[len(v)//2]:.4f}  all {['%.4f' % x for x in v]}")
+        print(f"{name:24s} {key} min {min(v):.4f}  med {sorted(v)[len(v)//2]:.4f}  all {['%.4f' % x for x in v]}")
 
 main()
