@@ -70,6 +70,31 @@ def synth_stream(seed: int, n_samples: int = STREAM_SAMPLES,
     return out
 
 
+def synth_two_bursts(seed: int, gap: int, n_samples: int = 4 * BLOCK_SIZE, amplitude: float = 0.5,
+                      noise: float = 0.05) -> np.ndarray:
+    """Two identical bursts `gap` samples apart (start to start) in one stream: both land in the
+    same demodulate() window, so the per-call dedupe (dsp.py:203-205) has real work to do."""
+    rng = np.random.default_rng(seed)
+    payload = OTA_PACKETS[int(rng.integers(0, len(OTA_PACKETS)))]
+    sym = np.concatenate([np.tile(np.array([1, 0], dtype=np.uint8), 16), packet_bits(payload),
+                          np.zeros(8, dtype=np.uint8)])
+    chips = np.repeat(sym, SYMBOL_LENGTH)
+    start = BLOCK_SIZE + int(rng.integers(0, 2000))
+    cfo = float(rng.uniform(-2000.0, 2000.0))
+    freq = np.full(n_samples, -SAMPLE_RATE / 4.0 + cfo)
+    on = np.zeros(n_samples)
+    for s0 in (start, start + gap):
+        on[s0:s0 + chips.size] = 1.0
+        freq[s0:s0 + chips.size] += np.where(chips == 1, 4800.0, -4800.0)
+    phase = np.cumsum(freq) * (2.0 * np.pi / SAMPLE_RATE)
+    x = amplitude * on * np.exp(1j * phase)
+    x = x + noise * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+    out = np.empty(2 * n_samples, dtype=np.uint8)
+    out[0::2] = np.clip(np.rint(x.real * 127.6 + 127.4), 0, 255).astype(np.uint8)
+    out[1::2] = np.clip(np.rint(x.imag * 127.6 + 127.4), 0, 255).astype(np.uint8)
+    return out
+
+
 def synth_streams(seeds, n_samples: int = STREAM_SAMPLES) -> np.ndarray:
     """Stack of streams, shape [len(seeds), 2*n_samples] uint8."""
     seeds = list(seeds)

@@ -224,6 +224,34 @@ def test_batch_edge_q_equals_block_size(dsp, batchmod):
     assert sha(bd.bits(0)) == g["bits_sha256"]
 
 
+def test_two_bursts_in_one_window_dedupe_order(dsp, batchmod):
+    """Several matches with different and with identical bytes inside one call: the on-device
+    dedupe must keep exactly what dsp.py:203-205 keeps, in the reference's order."""
+    g = load_json("two_bursts.json")
+    seeds = sorted(g, key=int)
+    raws = np.stack([synth.synth_two_bursts(int(s), g[s]["gap"]) for s in seeds])
+    for i, s in enumerate(seeds):
+        assert sha(raws[i]) == g[s]["raw_sha256"]
+        assert_calls_equal(run_streaming(dsp.Demodulator(prod_cfg(dsp)), raws[i]), g[s]["calls"])
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), raws.shape[1] // 2 // 8192)
+    res = bd.demodulate(raws)
+    for i, s in enumerate(seeds):
+        assert_calls_equal(res[i], g[s]["calls"])
+        assert sha(bd.bits(i)) == g[s]["bits_sha256"]
+
+
+def test_dedupe_many_identical_records_one_call(dsp, batchmod):
+    """One stream repeated: every stream must produce the same packets (hash-table collisions
+    between streams must not merge records of different streams)."""
+    g = load_json("two_bursts.json")
+    raw = synth.synth_two_bursts(300, g["300"]["gap"])
+    n = 700
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), n, raw.size // 2 // 8192)
+    res = bd.demodulate(np.tile(raw, (n, 1)))
+    for i in range(n):
+        assert_calls_equal(res[i], g["300"]["calls"])
+
+
 def test_alt_symbol_length(dsp, batchmod):
     g = load_json("alt_s8_b1024.json")
     cfg = dsp.PacketConfig(**g["config"])

@@ -61,6 +61,14 @@ def test_block_512_edge_and_alt():
     assert sha(bits) == a["bits_sha256"]
 
 
+def test_two_bursts_in_one_window():
+    for seed, rec in load_json("two_bursts.json").items():
+        raw = synth.synth_two_bursts(int(seed), rec["gap"])
+        calls, bits, _ = CO.demod_stream(raw, CO.make_cfg())
+        assert_calls_equal(calls, rec["calls"])
+        assert sha(bits) == rec["bits_sha256"]
+
+
 def test_startup_quadrants():
     for name, rec in load_json("startup_quadrants.json").items():
         raw = np.frombuffer(bytes.fromhex(rec["raw"]), dtype=np.uint8)

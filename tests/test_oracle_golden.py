@@ -109,6 +109,17 @@ def test_edge_q_equals_block_size():
     assert_calls_equal(O.calls_from_oneshot(f, bits1, PROD), g["calls"])
 
 
+def test_two_bursts_in_one_window():
+    g = load_json("two_bursts.json")
+    for seed, rec in g.items():
+        raw = synth.synth_two_bursts(int(seed), rec["gap"])
+        assert sha(raw) == rec["raw_sha256"]
+        calls, bits = run_calls(O.OracleDemodulator(PROD), raw)
+        assert_calls_equal(calls, rec["calls"])
+        assert sha(O.pack_bits_le(bits)) == rec["bits_sha256"]
+        assert max(len(c) for c in calls) >= 2
+
+
 def test_alt_symbol_length_8():
     g = load_json("alt_s8_b1024.json")
     cfg = O.OracleConfig(**g["config"])

@@ -223,6 +223,18 @@ def main() -> None:
         json.dump({"in": [repr(float(v)) for v in q_in], "out": q_out.tolist(),
                    "rng42_out_packed": pack_le(rq_out).tobytes().hex()}, fh)
 
+    # ---- 9. two identical bursts inside one search window: per-call dedupe keeps the first
+    #         occurrence in phase-major order (dsp.py:175-186,203-205)
+    two = {}
+    for seed, gap in ((300, 2100), (301, 1700), (302, 2507)):
+        raw = synth.synth_two_bursts(seed, gap)
+        r = run_reference(raw, PROD)
+        two[str(seed)] = {"gap": gap, "raw_sha256": sha(raw), "calls": r["calls"],
+                          "bits_sha256": sha(pack_le(r["bits"]))}
+        print("two bursts seed", seed, [[(p["index"], p["data"]) for p in c] for c in r["calls"]])
+    with open(os.path.join(OUT, "two_bursts.json"), "w") as fh:
+        json.dump(two, fh, indent=0)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("golden fixtures written to", OUT)
