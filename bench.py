@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=33, help="8192-sample blocks per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--two-streams", action="store_true", help="one HIP stream per resident batch")
     return ap.parse_args()
 
 
@@ -120,17 +121,20 @@ def main():
     in_bytes = host.nbytes
     del host
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # --two-streams gives each resident batch its own HIP stream; measured: no gain, the demod
+    # kernel's persistent grid leaves no room for another batch's kernels to run beside it
+    tstreams = [torch.cuda.Stream() for _ in bds] if args.two_streams else [torch.cuda.current_stream()] * 2
+    streams = [t.cuda_stream for t in tstreams]
     for x in bds:
         x.set_timing(True)
 
     def run_steps(k):
         """k full steps; step i = bds[i%2].run + its results(); results(i) overlaps run(i+1)."""
         recs = None
-        bds[0].run(stream)
+        bds[0].run(streams[0])
         for i in range(1, k):
-            bds[i % 2].run(stream)
-            recs = bds[(i - 1) % 2].results()  # D2H of the packets + per-call ordering/dedupe
+            bds[i % 2].run(streams[i % 2])
+            recs = bds[(i - 1) % 2].results()  # D2H of the packets + per-call ordering
         recs = bds[(k - 1) % 2].results()
         return recs, bds[(k - 1) % 2]
 
