@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtldavis_hip.so")
+# RTLDAVIS_HIP_LIB overrides the path (A/B builds of the kernels); the default is the in-tree build
+LIB_PATH = os.environ.get("RTLDAVIS_HIP_LIB") or os.path.join(HERE, "librtldavis_hip.so")
 
 RD_MAX_PREAMBLE = 64
 RD_MAX_PKT_BYTES = 32

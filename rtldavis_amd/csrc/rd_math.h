@@ -110,6 +110,9 @@ struct rd_ptr_src {
 // RD_NPK of the nine FIR steps per output (4 pair sums, 5 multiply-adds) are issued as packed
 // fp32 (one instruction for re and im), the rest as scalar pairs.  Results are identical
 // either way (same IEEE operations per component).
+#ifndef RD_FENCE_EVERY
+#define RD_FENCE_EVERY 1
+#endif
 #ifndef RD_NPK_DEFAULT
 #define RD_NPK_DEFAULT 0
 #endif
@@ -210,7 +213,9 @@ RD_HD void rd_fast_step(const Src &win, rd_f2 *w, rd_run_state &st) {
         st.word = rd_shift_in_sign(st.word, num);  // one v_alignbit_b32; reversed after the loop
     }
     st.prev = acc;
-    RD_SCHED_FENCE();  // keep conversions next to their first use (register pressure)
+    // keep conversions next to their first use (register pressure): a scheduling fence every
+    // RD_FENCE_EVERY outputs
+    if ((R & (RD_FENCE_EVERY - 1)) == RD_FENCE_EVERY - 1) RD_SCHED_FENCE();
 }
 
 template <int R, int NPK, class Src>
@@ -373,30 +378,56 @@ RD_HD rd_i2 rd_f_int(const rd_stream_view &v, long t) {
     return rd_fir_int(y);
 }
 
+// The same decision through float64: U and taps*1e12 are integers below 2^53, so the FIR sums
+// are EXACT in double (|F| < 6.4e14).  The two products of the numerator are rounded once each
+// (relative 2^-53); when their difference clears 2^-51 (|p1| + |p2|) its sign is certain,
+// otherwise (an event of probability ~1e-15 per sample) the __int128 path decides.  About four
+// times fewer cycles than 64/128-bit integer arithmetic on the VALU.
+struct rd_dd2 {
+    double x, y;
+};
+
+RD_HD rd_dd2 rd_fir_f64_exact(const rd_dd2 *y) {
+    rd_dd2 f;
+    f.x = (double)RD_T0 * (y[0].x + y[8].x) + (double)RD_T1 * (y[1].x + y[7].x) + (double)RD_T2 * (y[2].x + y[6].x) +
+          (double)RD_T3 * (y[3].x + y[5].x) + (double)RD_T4 * y[4].x;
+    f.y = (double)RD_T0 * (y[0].y + y[8].y) + (double)RD_T1 * (y[1].y + y[7].y) + (double)RD_T2 * (y[2].y + y[6].y) +
+          (double)RD_T3 * (y[3].y + y[5].y) + (double)RD_T4 * y[4].y;
+    return f;  // every product and partial sum is an integer < 2^53: no rounding anywhere
+}
+
+RD_HD uint32_t rd_exact_bit_f64(rd_dd2 n, rd_dd2 np) {
+    const double p1 = n.y * np.x, p2 = n.x * np.y;
+    const double d = p1 - p2;
+    const double guard = 4.440892098500626e-16 * (__builtin_fabs(p1) + __builtin_fabs(p2));  // 2^-51
+    if (d > guard) return 0u;
+    if (d < -guard) return 1u;
+    rd_i2 ni = {(int64_t)n.x, (int64_t)n.y}, npi = {(int64_t)np.x, (int64_t)np.y};
+    return rd_exact_bit(ni, npi);
+}
+
 // Exact bits of the 8-sample group starting at t0 (t0 % 8 == 0) from ten preloaded dwords that
 // hold samples t0-10 .. t0+9 (dword d = samples t0-10+2d, t0-9+2d as I,Q,I,Q bytes).  Used by
 // k_fixup so that all of a group's input is fetched with independent, aligned 4-byte loads.
 // `first_valid`: samples with index < first_valid (zero history) read as y = 0.
 RD_HD uint32_t rd_exact_group_dw(const uint32_t *dw, long t0, int count, long first_valid) {
-    rd_i2 y[9];
-    auto sample = [&](int i) {  // i = index into the 20-sample window
-        const long n = t0 - 10 + i;
-        rd_i2 z = {0, 0};
-        if (n < first_valid) return z;
-        const uint32_t d = dw[i >> 1] >> (16 * (i & 1));
-        return rd_rot_int((int)(d & 0xFF), (int)((d >> 8) & 0xFF), (int)(n & 3));
-    };
+    rd_dd2 y[17];  // rotated integer samples t0-10 .. t0+6 as doubles (t0 % 4 == 0: static phases)
 #pragma unroll
-    for (int m = 0; m < 9; m++) y[m] = sample(m);
-    rd_i2 prev = rd_fir_int(y);  // f[t0-1]
+    for (int i = 0; i < 17; i++) {
+        const long n = t0 - 10 + i;
+        const uint32_t d = dw[i >> 1] >> (16 * (i & 1));
+        double a = (double)(5 * (int)(d & 0xFF) - 637), b = (double)(5 * (int)((d >> 8) & 0xFF) - 637);
+        if (n < first_valid) { a = 0.0; b = 0.0; }  // zero history: y = 0 (5k-637 is never 0 otherwise)
+        const int ph = (i + 2) & 3;  // (t0 - 10 + i) mod 4
+        y[i].x = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
+        y[i].y = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
+    }
+    rd_dd2 prev = rd_fir_f64_exact(&y[0]);  // f[t0-1] uses samples t0-10 .. t0-2
     uint32_t word = 0;
 #pragma unroll
     for (int r = 0; r < RD_GROUP; r++) {
-#pragma unroll
-        for (int m = 0; m < 8; m++) y[m] = y[m + 1];
-        y[8] = sample(r + 9);  // sample t0+r-1
-        const rd_i2 cur = rd_fir_int(y);  // f[t0+r]
-        if (r < count) word |= rd_exact_bit(prev, cur) << r;
+        const rd_dd2 cur = rd_fir_f64_exact(&y[r + 1]);  // f[t0+r] uses samples t0+r-9 .. t0+r-1
+        if (r < count) word |= rd_exact_bit_f64(prev, cur) << r;
         prev = cur;
     }
     return word;
