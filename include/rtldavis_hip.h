@@ -56,6 +56,21 @@ typedef struct rd_packet {
     double snr;
 } rd_packet;
 
+/* One CRC-valid message of protocol.Parser.parse's front half (/root/reference/src/rtldavis/
+ * protocol.py:282-318): bytes bit-reversed (:290), CRC-16-CCITT over data[2:] == 0 (:297),
+ * frequency error from the mean discriminator output over the preamble window (:304-311). */
+typedef struct rd_parsed {
+    int32_t stream;
+    int32_t call;
+    int32_t index;     /* Packet.index of the packet it came from */
+    int32_t freq_err;  /* Hz, -int(mean * sample_rate / 2pi) */
+    int32_t id;        /* transmitter id: data[2] & 7 after the bit swap (:318) */
+    int32_t nbytes;    /* length of data[] = packet bytes - 2 */
+    uint8_t data[RD_MAX_PKT_BYTES]; /* bit-swapped message bytes, sync word removed (msg_data, :317) */
+    double rssi;
+    double snr;
+} rd_parsed;
+
 /* Mean per-launch duration of the kernels of the rd_batch_run calls made since timing was
  * enabled or last read (HIP events recorded on each run's stream). */
 typedef struct rd_timing {
@@ -124,6 +139,10 @@ int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n);
 int rd_batch_copy_bits(rd_batch *b, int stream, uint8_t *out, size_t nbytes);
 /* Full-precision discriminator output d[t0 .. t0+n) of one stream (py:76-90), float64. */
 int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out, size_t n);
+/* Parser.parse front half on the device for the whole batch (opt-in, before rd_batch_run):
+ * after a run, rd_batch_parsed returns the CRC-valid messages sorted like rd_batch_results. */
+int rd_batch_set_parse(rd_batch *b, int enabled);
+int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n);
 /* Enable per-kernel HIP-event timing (five events per run on the run's stream); get_timing
  * synchronises, returns the mean over the runs recorded so far and starts a new window. */
 int rd_batch_set_timing(rd_batch *b, int enabled);

@@ -31,6 +31,12 @@ class RdPacket(C.Structure):
                 ("data", C.c_uint8 * RD_MAX_PKT_BYTES), ("rssi", C.c_double), ("snr", C.c_double)]
 
 
+class RdParsed(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("call", C.c_int32), ("index", C.c_int32), ("freq_err", C.c_int32),
+                ("id", C.c_int32), ("nbytes", C.c_int32), ("data", C.c_uint8 * RD_MAX_PKT_BYTES),
+                ("rssi", C.c_double), ("snr", C.c_double)]
+
+
 class RdTiming(C.Structure):
     _fields_ = [("demod_ms", C.c_float), ("fixup_ms", C.c_float), ("search_ms", C.c_float),
                 ("slice_ms", C.c_float), ("total_ms", C.c_float), ("runs", C.c_int32)]
@@ -57,6 +63,8 @@ SIGNATURES = {
     "rd_batch_results": (C.c_int, [_P, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),
     "rd_batch_copy_bits": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "rd_batch_copy_discriminated": (C.c_int, [_P, C.c_int, C.c_size_t, _P, C.c_size_t]),
+    "rd_batch_set_parse": (C.c_int, [_P, C.c_int]),
+    "rd_batch_parsed": (C.c_int, [_P, C.POINTER(RdParsed), C.c_int, C.POINTER(C.c_int)]),
     "rd_batch_set_timing": (C.c_int, [_P, C.c_int]),
     "rd_batch_get_timing": (C.c_int, [_P, C.POINTER(RdTiming)]),
     "rd_batch_get_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -18,6 +18,12 @@ RD_PACKET_DTYPE = np.dtype([("stream", "<i4"), ("call", "<i4"), ("index", "<i4")
 assert RD_PACKET_DTYPE.itemsize == C.sizeof(_lib.RdPacket)
 
 
+RD_PARSED_DTYPE = np.dtype([("stream", "<i4"), ("call", "<i4"), ("index", "<i4"), ("freq_err", "<i4"),
+                            ("id", "<i4"), ("nbytes", "<i4"), ("data", "u1", (_lib.RD_MAX_PKT_BYTES,)),
+                            ("rssi", "<f8"), ("snr", "<f8")])
+assert RD_PARSED_DTYPE.itemsize == C.sizeof(_lib.RdParsed)
+
+
 class BatchDemodulator:
     def __init__(self, cfg: PacketConfig, n_streams: int, n_blocks: int, device: Optional[int] = None) -> None:
         self.cfg = cfg
@@ -56,6 +62,25 @@ class BatchDemodulator:
     def run(self, hip_stream: int = 0) -> None:
         """Launch the whole path (asynchronous) on a hipStream_t given as an integer handle."""
         _lib.check(_lib.lib().rd_batch_run(self._b, C.c_void_p(hip_stream or None)))
+
+    def set_parse(self, enabled: bool) -> None:
+        """Also run the front half of protocol.Parser.parse (protocol.py:282-318) on the device
+        for every packet: bit swap, CRC gate, frequency error.  Call before run()."""
+        _lib.check(_lib.lib().rd_batch_set_parse(self._b, int(bool(enabled))))
+
+    def parsed(self) -> np.ndarray:
+        """CRC-valid messages of the last run (structured array, fields of rd_parsed), sorted by
+        (stream, call, reference order): what Parser.parse keeps before sensor decoding."""
+        cap = max(1024, 4 * self.n_streams)
+        while True:
+            buf = (_lib.RdParsed * cap)()
+            n = C.c_int(0)
+            rc = _lib.lib().rd_batch_parsed(self._b, buf, cap, C.byref(n))
+            if rc == _lib.RD_ERR_CAPACITY:
+                cap = n.value + 1024
+                continue
+            _lib.check(rc)
+            return np.frombuffer(buf, dtype=RD_PARSED_DTYPE, count=n.value).copy()
 
     def set_timing(self, enabled: bool) -> None:
         _lib.check(_lib.lib().rd_batch_set_timing(self._b, int(bool(enabled))))

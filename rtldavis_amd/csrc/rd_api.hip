@@ -134,6 +134,7 @@ static int make_devcfg(const rd_config *c, rd_devcfg *d) {
     if (L > 0x3FFFFFFF) return fail(RD_ERR_ARG, "buffer_length too large");
     d->L = (int32_t)L;
     d->nbytes = (c->packet_symbols + 7) / 8;
+    d->fs = (double)c->bit_rate * (double)c->symbol_length;
     d->pre_mask = 0;
     for (int i = 0; i < c->preamble_symbols; i++) {
         if (c->preamble[i] > 1) return fail(RD_ERR_ARG, "preamble symbols must be 0 or 1");
@@ -227,6 +228,8 @@ struct rd_batch {
     rd_match *d_matches = nullptr;
     rd_packet *d_recs = nullptr;
     rd_dedupe_ws ws = {};
+    bool parse = false;              // Parser.parse front half on the device (rd_batch_set_parse)
+    rd_parsed *d_parsed = nullptr;   // rec_cap entries
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> evs;  // 5 events per timed run, read back in rd_batch_get_timing
@@ -334,6 +337,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs);
         free_dedupe_ws(b->ws);
+        hipFree(b->d_parsed);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
@@ -372,6 +376,10 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     if (b->timing) hipEventRecord(b->ev[3], st);
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
                     b->d_recs, b->rec_cap, b->ws, b->d_cnt, st);
+    if (b->parse) {
+        if (!b->d_parsed) hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed));
+        if (b->d_parsed) rd_launch_parse(lay, b->dc, b->ws.final_recs, b->rec_cap, b->d_parsed, b->d_cnt, st);
+    }
     if (b->timing) hipEventRecord(b->ev[4], st);
     // results come back with the run: counters plus as many records as the last run produced
     // (+25 %); rd_batch_results fetches the remainder if this run produced more.
@@ -441,6 +449,7 @@ static int batch_finish(rd_batch *b) {
         if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
             hipFree(b->d_matches); hipFree(b->d_recs); hipHostFree(b->h_recs_pin);
             free_dedupe_ws(b->ws);
+            hipFree(b->d_parsed); b->d_parsed = nullptr;
             b->match_cap = b->h_cnt[RD_CNT_MATCH] + b->h_cnt[RD_CNT_MATCH] / 4 + 1024;
             b->rec_cap = 2 * b->match_cap;
             HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
@@ -454,7 +463,7 @@ static int batch_finish(rd_batch *b) {
             b->last_match = b->h_cnt[RD_CNT_MATCH];
             return RD_OK;
         }
-        const uint32_t zero[3] = {0, 0, 0};  // matches, raw records, final records
+        const uint32_t zero[4] = {0, 0, 0, 0};  // matches, raw records, final records, parsed
         HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
         batch_search_slice(b, st);
     }
@@ -513,6 +522,40 @@ extern "C" int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, d
     rc = copy_d2h(out, d, n * sizeof(double), b->stream);
     hipFree(d);
     return rc;
+}
+
+extern "C" int rd_batch_set_parse(rd_batch *b, int enabled) {
+    if (!b) return fail(RD_ERR_ARG, "null batch");
+    b->parse = enabled != 0;
+    return RD_OK;
+}
+
+extern "C" int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n) {
+    if (!b || !n) return fail(RD_ERR_ARG, "null argument");
+    if (!b->parse) return fail(RD_ERR_STATE, "rd_batch_set_parse(b, 1) must precede rd_batch_run");
+    int rc = batch_finish(b);
+    if (rc) return rc;
+    const uint32_t np = std::min(b->h_cnt[RD_CNT_PARSED], b->rec_cap);
+    std::vector<rd_parsed> recs(np);
+    if (np) {
+        rc = copy_d2h(recs.data(), b->d_parsed, (size_t)np * sizeof(rd_parsed), b->stream);
+        if (rc) return rc;
+    }
+    const int S = b->dc.S;  // the order parse() sees: packets of a call in _slice's order
+    std::sort(recs.begin(), recs.end(), [S](const rd_parsed &x, const rd_parsed &y) {
+        if (x.stream != y.stream) return x.stream < y.stream;
+        if (x.call != y.call) return x.call < y.call;
+        const int px = x.index % S, py = y.index % S;
+        if (px != py) return px < py;
+        return x.index < y.index;
+    });
+    *n = (int)np;
+    if ((int)np > cap) return fail(RD_ERR_CAPACITY, "need room for %u messages", np);
+    if (np) {
+        if (!out) return fail(RD_ERR_ARG, "null out");
+        memcpy(out, recs.data(), (size_t)np * sizeof(rd_parsed));
+    }
+    return RD_OK;
 }
 
 extern "C" int rd_batch_set_timing(rd_batch *b, int enabled) {

@@ -6,7 +6,7 @@
 #include "../../include/rtldavis_hip.h"
 
 // counters[] slots (device uint32)
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_FINAL = 3, RD_CNT_SLOTS = 8 };
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_FINAL = 3, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
 
 // Geometry of the fused demod kernel
 #define RD_TILE_SAMPLES 2048  // 64 lanes x 32 samples: one wave iteration
@@ -29,6 +29,7 @@ struct rd_layout {
 struct rd_devcfg {
     int32_t S, P, K, B, L, PL, nbytes;  // symbol_length, preamble/packet symbols, block, buffer, preamble_length
     uint64_t pre_mask;                  // bit m = preamble symbol m
+    double fs;                          // sample rate = bit_rate * symbol_length (protocol.py:309)
 };
 
 struct rd_match {
@@ -63,6 +64,10 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
                      rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st);
+// Parser.parse front half (protocol.py:290-311) over the final records of a batch run:
+// CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
+void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *final_recs, uint32_t rec_cap,
+                     rd_parsed *parsed, uint32_t *counters, hipStream_t st);
 // d[t0 .. t0+n) of stream `stream` in float64
 void rd_launch_disc(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
 // f[t0 .. t0+n) (interleaved re,im) of stream `stream` in float64

@@ -789,6 +789,101 @@ void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_str
 }
 
 // ------------------------------------------------------------------------------------------
+// Parser.parse front half (protocol.py:282-311), batch mode.
+// k_parse_select: one lane per final record: bit-reverse every byte (:290, :79-83), CRC-16-CCITT
+// (poly 0x1021, init 0; crc.py:19-26) over data[2:] must be 0 (:297); survivors are compacted.
+// k_freq_err: one wave per survivor: mean of discriminated[index : index + preamble_length]
+// (:304-311) in float64, where discriminated covers absolute samples [(call-1)B, (call+1)B).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rd_swap_bits8(uint32_t b) {  // protocol.py:79-83
+    b = ((b & 0xF0) >> 4) | ((b & 0x0F) << 4);
+    b = ((b & 0xCC) >> 2) | ((b & 0x33) << 2);
+    b = ((b & 0xAA) >> 1) | ((b & 0x55) << 1);
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_parse_select(const rd_packet *recs, uint32_t rec_cap, rd_parsed *parsed,
+                                                      uint32_t *counters) {
+    uint32_t count = counters[RD_CNT_FINAL];
+    if (count > rec_cap) count = rec_cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool ok = false;
+    uint8_t sw[RD_MAX_PKT_BYTES];
+    int nb = 0;
+    if (i < count) {
+        const rd_packet *r = &recs[i];
+        nb = r->nbytes;
+        uint32_t crc = 0;
+#pragma unroll
+        for (int k = 0; k < RD_MAX_PKT_BYTES; k++) {
+            const uint32_t b = k < nb ? rd_swap_bits8(r->data[k]) : 0u;
+            sw[k] = (uint8_t)b;
+            if (k >= 2 && k < nb) {  // crc.py:24-25, bitwise form
+                crc ^= b << 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++) crc = (crc & 0x8000) ? ((crc << 1) ^ 0x1021) & 0xFFFF : (crc << 1) & 0xFFFF;
+            }
+        }
+        ok = nb > 2 && crc == 0;
+    }
+    const uint64_t km = __ballot(ok);
+    if (!km) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[RD_CNT_PARSED], (uint32_t)__popcll(km));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (!ok) return;
+    const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
+    if (dst >= rec_cap) return;
+    const rd_packet *r = &recs[i];
+    rd_parsed *o = &parsed[dst];
+    o->stream = r->stream; o->call = r->call; o->index = r->index; o->freq_err = 0;
+    o->id = sw[2] & 7; o->nbytes = nb - 2;
+#pragma unroll
+    for (int k = 0; k < RD_MAX_PKT_BYTES; k++) o->data[k] = (k + 2 < RD_MAX_PKT_BYTES && k + 2 < nb) ? sw[k + 2] : 0;
+    o->rssi = r->rssi; o->snr = r->snr;
+}
+
+__global__ __launch_bounds__(256) void k_freq_err(rd_layout lay, rd_devcfg cfg, rd_parsed *parsed, uint32_t rec_cap,
+                                                  const uint32_t *counters) {
+    const int lane = threadIdx.x & 63;
+    uint32_t count = counters[RD_CNT_PARSED];
+    if (count > rec_cap) count = rec_cap;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
+        rd_parsed *o = &parsed[i];
+        rd_stream_view v;
+        v.base = lay.iq + (size_t)o->stream * lay.stream_stride;
+        v.valid_from = lay.valid_from;
+        v.n = lay.n_samples;
+        // discriminated[j] of call b is d[(b-1)B + j], j in [0, 2B) (py:134,156,162)
+        const long j0 = o->index;
+        long j1 = j0 + cfg.PL;
+        if (j1 > 2L * cfg.B) j1 = 2L * cfg.B;
+        const long t_base = ((long)o->call - 1) * cfg.B;
+        double sum = 0.0;
+        for (long j = j0 + lane; j < j1; j += 64) {
+            const long t = t_base + j;
+            sum += rd_disc_f64(rd_f_f64(v, t - 1), rd_f_f64(v, t));
+        }
+        sum = rd_wave_sum(sum);
+        if (lane == 0) {
+            const double mean = sum / (double)(j1 - j0);
+            o->freq_err = -(int32_t)((mean * cfg.fs) / (2.0 * 3.141592653589793));  // int(): toward zero
+        }
+    }
+}
+
+void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *final_recs, uint32_t rec_cap,
+                     rd_parsed *parsed, uint32_t *counters, hipStream_t st) {
+    hipLaunchKernelGGL(k_parse_select, dim3((rec_cap + 255) / 256), dim3(256), 0, st, final_recs, rec_cap, parsed,
+                       counters);
+    uint32_t wgs = (rec_cap + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(k_freq_err, dim3(wgs), dim3(256), 0, st, lay, cfg, parsed, rec_cap, counters);
+}
+
+// ------------------------------------------------------------------------------------------
 // float64 values of d and f (state mirrors / parse()'s frequency error, protocol.py:307-311)
 // ------------------------------------------------------------------------------------------
 template <class View>

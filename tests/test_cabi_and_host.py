@@ -32,6 +32,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.RdPacket) == 4 * 4 + 32 + 2 * 8
     assert _lib.RdPacket.data.offset == 16 and _lib.RdPacket.rssi.offset == 48
     assert C.sizeof(_lib.RdTiming) == 24
+    assert C.sizeof(_lib.RdParsed) == 6 * 4 + 32 + 2 * 8
 
 
 def test_packet_config_mirrors_reference():
