@@ -217,7 +217,7 @@ def main():
                          "algorithmic_bytes_per_launch": samples_step * 2},
             "kernels_ms": {k[:-3]: round(float(tm[k]), 4) for k in ("demod_ms", "fixup_ms", "search_ms", "slice_ms",
                                                                      "total_ms")},
-            "fixup_samples_frac": round(cnt["fixup_groups"] * 8 / (n_streams * n_samples), 5),
+            "fixup_runs_frac": round(cnt["fixup_runs"] * 32 / (n_streams * n_samples), 5),
             "packets_per_step": len(recs), "verified_vs_reference_fixtures": verified,
             "h2d_s": round(t_h2d, 3),
         }

@@ -147,9 +147,9 @@ int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n);
  * synchronises, returns the mean over the runs recorded so far and starts a new window. */
 int rd_batch_set_timing(rd_batch *b, int enabled);
 int rd_batch_get_timing(rd_batch *b, rd_timing *out);
-/* Counters of the last run: 8-sample groups re-evaluated exactly (guard band), raw preamble
- * matches. */
-int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_groups, uint64_t *matches);
+/* Counters of the last run: 32-sample runs with at least one 8-sample group re-evaluated
+ * exactly (guard band), raw preamble matches. */
+int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t *matches);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage functions on host arrays (caller-allocated out-params, like the reference's).

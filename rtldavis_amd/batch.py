@@ -93,7 +93,7 @@ class BatchDemodulator:
     def counters(self) -> dict:
         f, m = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().rd_batch_get_counters(self._b, C.byref(f), C.byref(m)))
-        return {"fixup_groups": f.value, "matches": m.value}
+        return {"fixup_runs": f.value, "matches": m.value}
 
     # ---- results --------------------------------------------------------------------------
     def results(self) -> np.ndarray:

@@ -269,8 +269,8 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
     if (n_streams < 1 || n_blocks < 1) return fail(RD_ERR_ARG, "n_streams and n_blocks must be >= 1");
     const long n = (long)n_blocks * cfg->block_size;
     const uint64_t runs = (uint64_t)n_streams * ((n + RD_RUN - 1) / RD_RUN);
-    if (n > 0x7FFFFFF0L || runs > 0x3FFFFFFFull)
-        return fail(RD_ERR_ARG, "batch too large: the packed-bit array must stay below 4 GiB per batch");
+    if (n > 0x7FFFFFF0L || runs > 0x0FFFFFFFull)
+        return fail(RD_ERR_ARG, "batch too large: at most 2^28 32-sample runs (8.6e9 samples) per batch");
     rd_batch *b = new rd_batch();
     b->cfg = *cfg;
     b->dc = dc;
@@ -308,8 +308,8 @@ static int batch_alloc(rd_batch *b) {
     if (rc) return rc;
     const uint64_t runs = (uint64_t)b->n_streams * b->bits_stride;
     b->iq_bytes = (size_t)b->n_streams * b->n_samples * 2;
-    // guard-band list entries are 8-sample groups (4 per run); ~0.5 % of them on noise
-    b->fix_cap = (uint32_t)std::min<uint64_t>(4 * runs, std::max<uint64_t>(4096, runs / 4));
+    // guard-band list: one entry per flagged 32-sample run (~1.5 % of the runs on noise)
+    b->fix_cap = (uint32_t)std::min<uint64_t>(runs, std::max<uint64_t>(4096, runs / 8));
     // ~16 raw matches per 33-block stream on noise + one burst; the lists grow on overflow
     b->match_cap = (uint32_t)std::min<uint64_t>((uint64_t)b->n_streams * (8 + 1ull * b->n_blocks) + 1024, 1u << 26);
     b->rec_cap = 2 * b->match_cap;
@@ -441,7 +441,7 @@ static int batch_finish(rd_batch *b) {
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, 1, st);
             uint32_t cap = b->fix_cap;  // mark handled
             HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
-            b->last_fix = (uint64_t)b->n_streams * b->bits_stride * 4;
+            b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
             redo_search = true;
         } else if (attempt == 0) {
             b->last_fix = b->h_cnt[RD_CNT_FIX];
@@ -653,7 +653,7 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_ring, ring_bytes));
     HIPCHK(hipMemset(h->d_ring, 127, ring_bytes));
     HIPCHK(hipMalloc(&h->d_stage, 2 * B));
-    h->fix_cap = (uint32_t)(4 * ((B + 31) / 32));  // every 8-sample group of a block
+    h->fix_cap = (uint32_t)((B + 31) / 32);  // every run of a block
     h->match_cap = (uint32_t)(B + 1);
     h->rec_cap = (uint32_t)(B + 1);
     HIPCHK(hipMalloc(&h->d_blockbits, ((B + 31) / 32) * 4));

@@ -163,24 +163,19 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
             gmask = (run == 0 && !lay.hist_mode) ? 0xFu : rd_guard_mask(r);
             if (left < RD_RUN) gmask &= (1u << ((left + RD_GROUP - 1) / RD_GROUP)) - 1u;
         }
-        if (__ballot(gmask != 0)) {  // wave-uniform, ~60 % of the tiles on noise
-            // list entry = byte offset of the group's output byte in the bits array
-            const uint32_t byte0 = (uint32_t)(((size_t)s * lay.bits_stride + run) * 4);
-#pragma unroll
-            for (int g = 0; g < RD_GROUPS; g++) {
-                const bool flag = (gmask >> g) & 1;
-                const uint64_t fm = __ballot(flag);
-                if (!fm) continue;
-                const uint32_t nf = (uint32_t)__popcll(fm);
-                if (npend + nf > RD_PEND) {
-                    rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
-                    npend = 0;
-                }
-                if (flag)
-                    mypend[npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0))] = byte0 + g;
-                npend += nf;
+        const uint64_t fm = __ballot(gmask != 0);
+        if (fm) {  // wave-uniform, ~60 % of the tiles on noise
+            // one list entry per flagged run: (word index in the bits array) << 4 | group mask
+            const uint32_t nf = (uint32_t)__popcll(fm);
+            if (npend + nf > RD_PEND) {
+                rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
+                npend = 0;
             }
+            if (gmask)
+                mypend[npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0))] =
+                    ((uint32_t)((size_t)s * lay.bits_stride + run) << 4) | gmask;
+            npend += nf;
         }
         s = ns;
         ti = nti;
@@ -249,25 +244,30 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
             v.base = lay.iq + (size_t)s * lay.stream_stride;
             const long left = (long)lay.n_samples - t0;
             lay.bits[(size_t)s * lay.bits_stride + run] = rd_exact_run(v, t0, left < RD_RUN ? (int)left : RD_RUN);
-        } else {  // listed groups of 8 samples, one output byte each
-            const uint32_t off = fix_list[i];
-            const uint32_t bytes_per_stream = (uint32_t)(lay.bits_stride * 4);
-            const uint32_t s = off / bytes_per_stream;
-            const long t0 = (long)(off - s * bytes_per_stream) * RD_GROUP;
+        } else {  // listed runs: word index << 4 | mask of the 8-sample groups to re-evaluate
+            const uint32_t e = fix_list[i];
+            const uint32_t widx = e >> 4;
+            const uint32_t s = widx / (uint32_t)lay.bits_stride;
+            const uint32_t run = widx - s * (uint32_t)lay.bits_stride;
             v.base = lay.iq + (size_t)s * lay.stream_stride;
-            const long left = (long)lay.n_samples - t0;
-            const int count = left < RD_GROUP ? (int)left : RD_GROUP;
-            // samples t0-10 .. t0+9 = 40 bytes at a 4-byte aligned address: ten independent loads.
-            // Dwords wholly before the first readable sample are not touched (no history there).
-            const uint8_t *p = v.base + 2 * (t0 - 10);
-            uint32_t dw[10];
+            for (int g = 0; g < RD_GROUPS; g++) {
+                if (!((e >> g) & 1)) continue;
+                const long t0 = (long)run * RD_RUN + g * RD_GROUP;
+                const long left = (long)lay.n_samples - t0;
+                if (left <= 0) break;
+                const int count = left < RD_GROUP ? (int)left : RD_GROUP;
+                // samples t0-10 .. t0+9 = 40 bytes at a 4-byte aligned address: ten independent loads.
+                // Dwords wholly before the first readable sample are not touched (no history there).
+                const uint8_t *p = v.base + 2 * (t0 - 10);
+                uint32_t dw[10];
 #pragma unroll
-            for (int d = 0; d < 10; d++) {
-                const long n_hi = t0 - 10 + 2 * d + 1;  // last sample in this dword
-                dw[d] = (n_hi >= v.valid_from && t0 - 10 + 2 * d < (long)lay.n_samples + 8)
-                            ? *(const uint32_t *)(p + 4 * d) : 0u;
+                for (int d = 0; d < 10; d++) {
+                    const long n_hi = t0 - 10 + 2 * d + 1;  // last sample in this dword
+                    dw[d] = (n_hi >= v.valid_from && t0 - 10 + 2 * d < (long)lay.n_samples + 8)
+                                ? *(const uint32_t *)(p + 4 * d) : 0u;
+                }
+                ((uint8_t *)lay.bits)[(size_t)widx * 4 + g] = (uint8_t)rd_exact_group_dw(dw, t0, count, v.valid_from);
             }
-            ((uint8_t *)lay.bits)[off] = (uint8_t)rd_exact_group_dw(dw, t0, count, v.valid_from);
         }
     }
 }

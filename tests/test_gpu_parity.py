@@ -61,7 +61,7 @@ def test_batch_streams_bits_and_packets(dsp, batchmod, golden_streams):
             assert np.array_equal(bits, full[f"seed{seed}"])
         assert_calls_equal(res[i], dense_calls(g["calls"], synth.BLOCKS_PER_STREAM))
     c = bd.counters()
-    assert 0 < c["fixup_groups"] < 0.05 * len(seeds) * 4 * 8448
+    assert 0 < c["fixup_runs"] < 0.1 * len(seeds) * 8448
 
 
 def test_batch_matches_c_oracle_51_channels(dsp, batchmod):
