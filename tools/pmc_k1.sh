@@ -1,16 +1,18 @@
-# PMC pass for k_demod_bits (own run: counters only, no traces)
+# SQ counters of k_demod_bits under the bench load (own run: counters only)
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq
 rm -rf $OUT
-RD_K1_DEBUG=${2:-0} rocprofv3 --pmc $3 --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/step_profile.py 4096 notiming > $OUT.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT.log 2>&1
 python3 - <<PY
-import csv, glob, collections
-files = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)
-agg = collections.defaultdict(list)
-for f in files:
+import csv, glob, collections, os
+root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_sq"
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_demod_bits' in r['Kernel_Name']:
-            agg[r['Counter_Name']].append(float(r['Counter_Value']))
-for k, v in agg.items():
-    print(f"$1 {k:28s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("kernel,counter,mean_value,n")
+for k, d in agg.items():
+    if "rocclr" in k: continue
+    for c, v in sorted(d.items()):
+        print(f"{k},{c},{sum(v)/len(v):.1f},{len(v)}")
 PY
