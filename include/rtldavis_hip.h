@@ -143,8 +143,10 @@ int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out,
  * after a run, rd_batch_parsed returns the CRC-valid messages sorted like rd_batch_results. */
 int rd_batch_set_parse(rd_batch *b, int enabled);
 int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n);
-/* Enable per-kernel HIP-event timing (five events per run on the run's stream); get_timing
- * synchronises, returns the mean over the runs recorded so far and starts a new window. */
+/* HIP-event timing on the run's stream.  enabled = 1: the demod kernel and the whole run (three
+ * events per run; each event between two kernels costs ~6 us of GPU idle time); 2: every stage
+ * (five events); 0: off.  get_timing synchronises, returns the mean over the runs recorded so
+ * far and starts a new window (stages not timed read 0). */
 int rd_batch_set_timing(rd_batch *b, int enabled);
 int rd_batch_get_timing(rd_batch *b, rd_timing *out);
 /* Counters of the last run: 32-sample runs with at least one 8-sample group re-evaluated

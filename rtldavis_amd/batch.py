@@ -82,8 +82,9 @@ class BatchDemodulator:
             _lib.check(rc)
             return np.frombuffer(buf, dtype=RD_PARSED_DTYPE, count=n.value).copy()
 
-    def set_timing(self, enabled: bool) -> None:
-        _lib.check(_lib.lib().rd_batch_set_timing(self._b, int(bool(enabled))))
+    def set_timing(self, level) -> None:
+        """0/False: off; 1/True: demod kernel + whole run (3 events); 2: every stage (5 events)."""
+        _lib.check(_lib.lib().rd_batch_set_timing(self._b, int(level)))
 
     def timing(self) -> dict:
         t = _lib.RdTiming()

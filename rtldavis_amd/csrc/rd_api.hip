@@ -221,7 +221,7 @@ struct rd_batch {
     int n_streams, n_blocks;
     long n_samples;      // per stream
     size_t bits_stride;  // words per stream
-    bool dev_ready = false, fast_ok = false, ran = false, timing = false;
+    bool dev_ready = false, fast_ok = false, ran = false, timing = false, timing_detail = false;
     uint8_t *d_iq = nullptr;
     size_t iq_bytes = 0;
     uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
@@ -373,7 +373,7 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     const long B = b->dc.B, L = b->dc.L;
     rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
                      b->dc, b->d_matches, b->match_cap, b->d_cnt, st);
-    if (b->timing) hipEventRecord(b->ev[3], st);
+    if (b->timing && b->timing_detail) hipEventRecord(b->ev[3], st);
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
                     b->d_recs, b->rec_cap, b->ws, b->d_cnt, st);
     if (b->parse) {
@@ -417,7 +417,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, b->d_cnt, st);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
     rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, b->fast_ok ? 0 : 1, st);
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[2], st));
+    if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
     batch_search_slice(b, st);
     HIPCHK(hipGetLastError());
     b->ran = true;
@@ -561,6 +561,7 @@ extern "C" int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n) {
 extern "C" int rd_batch_set_timing(rd_batch *b, int enabled) {
     if (!b) return fail(RD_ERR_ARG, "null batch");
     b->timing = enabled != 0;
+    b->timing_detail = enabled >= 2;  // 1: demod kernel and total only (3 events per run); 2: every stage
     b->ev_runs = 0;
     return RD_OK;
 }
@@ -575,11 +576,13 @@ extern "C" int rd_batch_get_timing(rd_batch *b, rd_timing *out) {
     rd_timing t = {};
     for (size_t r = 0; r < b->ev_runs; r++) {
         hipEvent_t *e = &b->evs[5 * r];
-        float v[5];
+        float v[5] = {0, 0, 0, 0, 0};
         HIPCHK(hipEventElapsedTime(&v[0], e[0], e[1]));
-        HIPCHK(hipEventElapsedTime(&v[1], e[1], e[2]));
-        HIPCHK(hipEventElapsedTime(&v[2], e[2], e[3]));
-        HIPCHK(hipEventElapsedTime(&v[3], e[3], e[4]));
+        if (b->timing_detail) {
+            HIPCHK(hipEventElapsedTime(&v[1], e[1], e[2]));
+            HIPCHK(hipEventElapsedTime(&v[2], e[2], e[3]));
+            HIPCHK(hipEventElapsedTime(&v[3], e[3], e[4]));
+        }
         HIPCHK(hipEventElapsedTime(&v[4], e[0], e[4]));
         t.demod_ms += v[0]; t.fixup_ms += v[1]; t.search_ms += v[2]; t.slice_ms += v[3]; t.total_ms += v[4];
     }
