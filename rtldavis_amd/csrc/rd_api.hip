@@ -625,6 +625,7 @@ struct rd_demod {
     rd_packet *d_recs = nullptr;
     rd_dedupe_ws ws = {};
     double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
+    double *h_tmp = nullptr;        // pinned mirror of d_tmp (state accessors)
     uint8_t *h_in = nullptr;        // pinned staging of one input block
     uint32_t *h_cnt = nullptr;      // pinned
     rd_packet *h_recs = nullptr;    // pinned, rec_cap entries
@@ -671,6 +672,7 @@ static int demod_alloc(rd_demod *h) {
     { int rc2 = alloc_dedupe_ws(h->ws, h->rec_cap); if (rc2) return rc2; }
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&h->h_in, 16 * B, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_tmp, 2 * (2 * B + 2) * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     h->dev_ready = true;
@@ -684,7 +686,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_recs); hipFree(h->d_tmp);
         free_dedupe_ws(h->ws);
-        hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs);
+        hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs); hipHostFree(h->h_tmp);
     }
     delete h;
 }
@@ -835,7 +837,10 @@ extern "C" int rd_copy_discriminated(rd_demod *h, double *out, size_t n) {
     if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), 0, -(long)B, 2 * (long)B, h->d_tmp, nullptr);
     else rd_launch_cplx_disc(demod_clayout(h, h->seen - 1), -(long)B, 2 * (long)B, h->d_tmp, nullptr);
     HIPCHK(hipGetLastError());
-    return copy_d2h(out, h->d_tmp, n * sizeof(double), nullptr);
+    int rc = copy_d2h(h->h_tmp, h->d_tmp, n * sizeof(double), nullptr);  // pinned: no staging, polling wait
+    if (rc) return rc;
+    memcpy(out, h->h_tmp, n * sizeof(double));
+    return RD_OK;
 }
 
 extern "C" int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_complex) {
@@ -850,7 +855,10 @@ extern "C" int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_c
     if (!h->cplx_mode) rd_launch_filtered(demod_layout(h, h->seen - 1), 0, -1, (long)B + 1, h->d_tmp, nullptr);
     else rd_launch_cplx_filtered(demod_clayout(h, h->seen - 1), -1, (long)B + 1, h->d_tmp, nullptr);
     HIPCHK(hipGetLastError());
-    return copy_d2h(out_interleaved, h->d_tmp, 2 * n_complex * sizeof(double), nullptr);
+    int rc = copy_d2h(h->h_tmp, h->d_tmp, 2 * n_complex * sizeof(double), nullptr);
+    if (rc) return rc;
+    memcpy(out_interleaved, h->h_tmp, 2 * n_complex * sizeof(double));
+    return RD_OK;
 }
 
 extern "C" int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n) {
@@ -862,8 +870,10 @@ extern "C" int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n) {
         return RD_OK;
     }
     std::vector<uint32_t> words((L + 31) / 32);
-    int rc = copy_d2h(words.data(), h->d_win[h->cur_win], words.size() * 4, nullptr);
+    if (words.size() * 4 > 2 * (2 * (size_t)h->dc.B + 2) * sizeof(double)) return fail(RD_ERR_ARG, "window too large");
+    int rc = copy_d2h(h->h_tmp, h->d_win[h->cur_win], words.size() * 4, nullptr);
     if (rc) return rc;
+    memcpy(words.data(), h->h_tmp, words.size() * 4);
     for (size_t t = 0; t < L; t++) out[t] = (uint8_t)((words[t >> 5] >> (t & 31)) & 1u);  // unpack only
     return RD_OK;
 }

@@ -147,6 +147,48 @@ def test_batch_small_and_ragged_shapes(dsp, batchmod):
             assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]], (B, nb, i)
 
 
+@pytest.mark.parametrize("S,P,K,B,nb,ns", [
+    (4, 4, 12, 64, 9, 3),        # short preamble: a match every ~16 positions, lists overflow and grow
+    (5, 8, 40, 256, 6, 4),
+    (8, 12, 80, 1004, 3, 2),     # block size not a multiple of 8: exact kernel throughout
+    (14, 16, 80, 512, 10, 3),    # default block size, buffer_length = 4 blocks
+    (20, 24, 120, 4096, 2, 2),
+    (3, 6, 200, 96, 20, 2),      # 25-byte packets
+    (14, 6, 24, 8192, 2, 5),
+])
+def test_random_configs_against_c_oracle(dsp, batchmod, S, P, K, B, nb, ns):
+    """Generic PacketConfig coverage: random preamble, random noise input, batch and streaming
+    paths against the C oracle (bits, packets with order and dedupe, RSSI/SNR)."""
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(1000 * S + P)
+    pre = "".join(str(int(b)) for b in rng.integers(0, 2, size=P))
+    cfg = dsp.PacketConfig(19200, S, P, K, pre, B)
+    ocfg = CO.make_cfg(19200, S, P, K, pre, B)
+    raw = rng.integers(96, 160, size=(ns, 2 * B * nb), dtype=np.uint8)
+    want, wbits = CO.demod_batch(raw, ocfg, threads=2, want_bits=True, cap_per_stream=200000)
+    bd = batchmod.BatchDemodulator(cfg, ns, nb)
+    res = bd.demodulate(raw)
+    total = 0
+    for i in range(ns):
+        assert np.array_equal(bd.bits(i), wbits[i]), (i, "bits")
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+        exp = [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
+        assert got == exp, (i, len(got), len(exp))
+        flat = [p for ps in res[i] for p in ps]
+        for a, b in zip(flat, want[i]):
+            assert abs(a.rssi - b.rssi) < 1e-3 and (abs(a.snr - b.snr) < 1e-3 or (a.snr != a.snr and b.snr != b.snr))
+        total += len(got)
+    assert total > 0
+    # the same streams block by block through the streaming handle
+    dem = dsp.Demodulator(cfg)
+    try:
+        calls = run_streaming(dem, raw[0])
+    except BufferError:
+        return  # more than 64 packets in one call: the streaming wrapper's documented limit
+    got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(calls) for p in ps]
+    assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[0]]
+
+
 def test_batch_degenerate_inputs_take_the_exact_path(dsp, batchmod):
     """Low-amplitude and saturated inputs put most runs inside the guard band: the guard
     list overflows and every run is re-evaluated exactly.  Bits must still match."""
