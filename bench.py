@@ -224,7 +224,7 @@ def main():
             "packets_per_step": len(recs), "verified_vs_reference_fixtures": verified,
             "h2d_s": round(t_h2d, 3),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(uniq)
         print(json.dumps(out), flush=True)
     if world > 1:

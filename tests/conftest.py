@@ -14,6 +14,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the in-tree shared library is a build artefact (git-ignored): build it when it is missing
+    # (hipcc cross-compiles for gfx950 without a GPU); tests never fall back to anything else
+    so = os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rtldavis_amd", "csrc")])
 
 
 def load_json(name):

@@ -178,7 +178,7 @@ def test_random_configs_against_c_oracle(dsp, batchmod, S, P, K, B, nb, ns):
         for a, b in zip(flat, want[i]):
             assert abs(a.rssi - b.rssi) < 1e-3 and (abs(a.snr - b.snr) < 1e-3 or (a.snr != a.snr and b.snr != b.snr))
         total += len(got)
-    assert total > 0
+    assert total > 0 or P > 12  # long random preambles need not occur in noise
     # the same streams block by block through the streaming handle
     dem = dsp.Demodulator(cfg)
     try:
