@@ -482,6 +482,26 @@ __device__ __forceinline__ uint32_t rd_bit_at(const uint32_t *w, long nwords, lo
 // Writes one record (all fields except RSSI/SNR, which k_rssi fills for the survivors).
 __device__ __forceinline__ void rd_write_record(rd_packet *o, const uint32_t *w, long nwords, long pos,
                                                 const rd_devcfg &cfg, int stream, int call, long q) {
+    if (cfg.K == 80 && cfg.S == 14) {
+        // Davis packet: 80 bit reads with compile-time offsets, all issued before the first use
+        // (the generic loop below waits for every load in turn: 80 memory latencies per record)
+        uint32_t word[80];
+#pragma unroll
+        for (int i = 0; i < 80; i++) word[i] = rd_word_at(w, nwords, (pos + 14L * i) >> 5);
+        uint32_t bytes[10];
+#pragma unroll
+        for (int bi = 0; bi < 10; bi++) {
+            uint32_t byte = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = bi * 8 + k;
+                byte = (byte << 1) | ((word[i] >> ((pos + 14L * i) & 31)) & 1u);
+            }
+            bytes[bi] = byte;
+        }
+#pragma unroll
+        for (int bi = 0; bi < RD_MAX_PKT_BYTES; bi++) o->data[bi] = bi < 10 ? (uint8_t)bytes[bi] : (uint8_t)0;
+    } else
     for (int bi = 0; bi < RD_MAX_PKT_BYTES; bi++) {
         uint32_t byte = 0;
         if (bi < cfg.nbytes)
