@@ -107,6 +107,17 @@ int rd_reset(rd_demod *h);
  * (phase-major search order, per-call dedupe, py:171-205).
  */
 int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_complex, rd_packet *out, int cap, int *n);
+/*
+ * Several receivers in lock step: n_streams independent Demodulators (one per SDR / hop channel)
+ * fed one block each per call, all streams in one set of launches.  State is carried per stream
+ * exactly as for rd_create.  iq: uint8 [n_streams][2 * block_size], stream-major; packets carry
+ * their stream number and come sorted by (stream, reference order).  This is the shape
+ * worker.py:34-54 would take with more than one dongle.
+ */
+int rd_create_multi(const rd_config *cfg, int n_streams, rd_demod **out);
+int rd_demod_blocks(rd_demod *h, const uint8_t *iq, size_t nbytes, rd_packet *out, int cap, int *n);
+/* discriminated (py:134) of one stream of a multi-stream handle */
+int rd_copy_discriminated_stream(rd_demod *h, int stream, double *out, size_t n);
 /* Lazily materialised mirrors of the reference's state arrays after the last call:
  * discriminated f64[2*block_size] (py:134), filtered complex128[block_size+1] as
  * interleaved doubles (py:133), quantized uint8[buffer_length] 0/1 (py:135). */

@@ -49,6 +49,9 @@ SIGNATURES = {
     "rd_device_count": (C.c_int, []),
     "rd_set_device": (C.c_int, [C.c_int]),
     "rd_create": (C.c_int, [C.POINTER(RdConfig), C.POINTER(_P)]),
+    "rd_create_multi": (C.c_int, [C.POINTER(RdConfig), C.c_int, C.POINTER(_P)]),
+    "rd_demod_blocks": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),
+    "rd_copy_discriminated_stream": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "rd_destroy": (None, [_P]),
     "rd_reset": (C.c_int, [_P]),
     "rd_demod_block": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),

@@ -615,7 +615,10 @@ struct rd_demod {
     bool dev_ready = false;
     bool cplx_mode = false;  // switched on by the first complex128 block, until reset
     long seen = 0;           // blocks demodulated since reset
-    // byte ring: [hdr 32 B][prev 2B][cur 2B][pad]; complex ring: [hdr 16][prev B][cur B] complex128
+    int NS = 1;              // independent streams fed in lock step (rd_create_multi)
+    size_t ring_stride = 0;  // bytes between the streams' rings
+    // per stream, byte ring: [hdr 32 B][prev 2B][cur 2B]; complex ring (NS == 1 only):
+    // [hdr 16][prev B][cur B] complex128
     uint8_t *d_ring = nullptr;
     double *d_cring = nullptr;
     uint8_t *d_stage = nullptr;  // staging for byte input while in complex mode
@@ -633,18 +636,24 @@ struct rd_demod {
     bool fast_ok = false;
 };
 
-extern "C" int rd_create(const rd_config *cfg, rd_demod **out) {
+extern "C" int rd_create_multi(const rd_config *cfg, int n_streams, rd_demod **out) {
     if (!out) return fail(RD_ERR_ARG, "null out");
     rd_devcfg dc;
     int rc = make_devcfg(cfg, &dc);
     if (rc) return rc;
+    if (n_streams < 1 || (uint64_t)n_streams * ((uint64_t)dc.B + 1) > 0x7FFFFFFFull)
+        return fail(RD_ERR_ARG, "n_streams out of range");
     rd_demod *h = new rd_demod();
     h->cfg = *cfg;
     h->dc = dc;
+    h->NS = n_streams;
+    h->ring_stride = ((32 + 4 * (size_t)dc.B) + 15) & ~(size_t)15;
     h->fast_ok = (dc.B % 8) == 0;
     *out = h;
     return RD_OK;
 }
+
+extern "C" int rd_create(const rd_config *cfg, rd_demod **out) { return rd_create_multi(cfg, 1, out); }
 
 static size_t ring_cur_off(const rd_demod *h) { return 32 + 2 * (size_t)h->dc.B; }
 
@@ -652,18 +661,18 @@ static int demod_alloc(rd_demod *h) {
     if (h->dev_ready) return RD_OK;
     int rc = ensure_device();
     if (rc) return rc;
-    const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L;
-    const size_t ring_bytes = 32 + 4 * B + RD_INPUT_PAD;
+    const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L, NS = (size_t)h->NS;
+    const size_t ring_bytes = NS * h->ring_stride + RD_INPUT_PAD;
     HIPCHK(hipMalloc(&h->d_ring, ring_bytes));
     HIPCHK(hipMemset(h->d_ring, 127, ring_bytes));
     HIPCHK(hipMalloc(&h->d_stage, 2 * B));
-    h->fix_cap = (uint32_t)((B + 31) / 32);  // every run of a block
-    h->match_cap = (uint32_t)(B + 1);
-    h->rec_cap = (uint32_t)(B + 1);
-    HIPCHK(hipMalloc(&h->d_blockbits, ((B + 31) / 32) * 4));
+    h->fix_cap = (uint32_t)(NS * ((B + 31) / 32));  // every run of a block
+    h->match_cap = (uint32_t)(NS * (B + 1));        // every position of every window: cannot overflow
+    h->rec_cap = h->match_cap;
+    HIPCHK(hipMalloc(&h->d_blockbits, NS * ((B + 31) / 32) * 4));
     for (int i = 0; i < 2; i++) {
-        HIPCHK(hipMalloc(&h->d_win[i], ((L + 31) / 32) * 4));
-        HIPCHK(hipMemset(h->d_win[i], 0, ((L + 31) / 32) * 4));
+        HIPCHK(hipMalloc(&h->d_win[i], NS * ((L + 31) / 32) * 4));
+        HIPCHK(hipMemset(h->d_win[i], 0, NS * ((L + 31) / 32) * 4));
     }
     HIPCHK(hipMalloc(&h->d_fix, (size_t)h->fix_cap * 4));
     HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
@@ -671,7 +680,7 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(rd_packet)));
     { int rc2 = alloc_dedupe_ws(h->ws, h->rec_cap); if (rc2) return rc2; }
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&h->h_in, 16 * B, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_in, std::max(16 * B, NS * 2 * B), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_tmp, 2 * (2 * B + 2) * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
@@ -697,7 +706,7 @@ extern "C" int rd_reset(rd_demod *h) {
     h->cplx_mode = false;
     if (h->dev_ready) {
         const size_t L = (size_t)h->dc.L;
-        for (int i = 0; i < 2; i++) HIPCHK(hipMemset(h->d_win[i], 0, ((L + 31) / 32) * 4));
+        for (int i = 0; i < 2; i++) HIPCHK(hipMemset(h->d_win[i], 0, (size_t)h->NS * ((L + 31) / 32) * 4));
     }
     return RD_OK;
 }
@@ -713,8 +722,8 @@ static long demod_valid_from(const rd_demod *h, long seen_before) {
 static rd_layout demod_layout(const rd_demod *h, long seen_before) {
     rd_layout l;
     l.iq = h->d_ring + ring_cur_off(h);
-    l.stream_stride = 0;
-    l.n_streams = 1;
+    l.stream_stride = h->ring_stride;
+    l.n_streams = h->NS;
     l.n_samples = (uint32_t)h->dc.B;
     l.hist_mode = seen_before > 0 ? 1 : 0;
     l.valid_from = demod_valid_from(h, seen_before);
@@ -742,13 +751,10 @@ static int demod_enter_cplx(rd_demod *h) {
     return RD_OK;
 }
 
-extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_complex, rd_packet *out, int cap,
-                              int *n) {
-    if (!h || !samples || !n) return fail(RD_ERR_ARG, "null argument");
-    const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L;
-    // py:32-36 / py:145-149
-    if ((is_complex && count != B) || (!is_complex && count != 2 * B))
-        return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu, expected %zu", count, is_complex ? B : 2 * B);
+// One block per stream (uint8: NS x 2B bytes, stream-major; complex128: single stream only).
+static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_packet *out, int cap, int *n) {
+    const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L, NS = (size_t)h->NS;
+    const size_t bw = (B + 31) / 32, lw = (L + 31) / 32;
     int rc = demod_alloc(h);
     if (rc) return rc;
     hipStream_t st = nullptr;
@@ -757,15 +763,16 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
         if (rc) return rc;
     }
     const long seen_before = h->seen;
-    // roll the raw ring left by one block (py:140,154): hdr <- tail of prev, prev <- cur
+    // roll the raw rings left by one block (py:140,154): hdr <- tail of prev, prev <- cur
     if (!h->cplx_mode) {
         uint8_t *r = h->d_ring;
+        const size_t rs = h->ring_stride;
         if (seen_before > 0) {
-            HIPCHK(hipMemcpyAsync(r, r + 32 + 2 * B - 32, 32, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(r + 32, r + 32 + 2 * B, 2 * B, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpy2DAsync(r, rs, r + 2 * B, rs, 32, NS, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpy2DAsync(r + 32, rs, r + 32 + 2 * B, rs, 2 * B, NS, hipMemcpyDeviceToDevice, st));
         }
-        memcpy(h->h_in, samples, 2 * B);
-        HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, h->h_in, 2 * B, hipMemcpyHostToDevice, st));
+        memcpy(h->h_in, samples, NS * 2 * B);
+        HIPCHK(hipMemcpy2DAsync(r + 32 + 2 * B, rs, h->h_in, 2 * B, 2 * B, NS, hipMemcpyHostToDevice, st));
     } else {
         double *r = h->d_cring;
         if (seen_before > 0) {
@@ -791,19 +798,19 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
     }
     // quantized <- roll(quantized, -B) with the new bits at the end (py:157,163-166)
     const int nw = h->cur_win ^ 1;
-    rd_launch_window_update(h->d_win[nw], h->d_win[h->cur_win], (long)L, h->d_blockbits, (long)B, st);
+    rd_launch_window_update(h->d_win[nw], h->d_win[h->cur_win], (long)L, h->d_blockbits, (long)B, h->NS, lw, bw, st);
     h->cur_win = nw;
     // whole-buffer search, keep q <= B (py:171-188,194)
-    rd_launch_search(h->d_win[nw], 0, 1, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
+    rd_launch_search(h->d_win[nw], lw, h->NS, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
     if (!h->cplx_mode)
-        rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], 0, (long)L, h->dc, h->d_matches, h->match_cap, 0, 0,
-                        (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
+        rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], lw, (long)L, h->dc, h->d_matches, h->match_cap, 0,
+                        0, (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
     else
         rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
                              (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
     HIPCHK(hipGetLastError());
     // counters and the first records come back with the block; polling wait (see wait_stream)
-    const uint32_t spec = std::min<uint32_t>(h->rec_cap, 32);
+    const uint32_t spec = std::min<uint32_t>(h->rec_cap, 32 * (uint32_t)NS);
     HIPCHK(hipMemcpyAsync(h->h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h->h_recs, h->ws.final_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
     rc = wait_stream(st);
@@ -825,8 +832,33 @@ extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, in
     return RD_OK;
 }
 
+extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_complex, rd_packet *out, int cap,
+                              int *n) {
+    if (!h || !samples || !n) return fail(RD_ERR_ARG, "null argument");
+    if (h->NS != 1) return fail(RD_ERR_STATE, "handle holds %d streams: use rd_demod_blocks", h->NS);
+    const size_t B = (size_t)h->dc.B;
+    // py:32-36 / py:145-149
+    if ((is_complex && count != B) || (!is_complex && count != 2 * B))
+        return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu, expected %zu", count, is_complex ? B : 2 * B);
+    return demod_blocks(h, samples, is_complex, out, cap, n);
+}
+
+extern "C" int rd_demod_blocks(rd_demod *h, const uint8_t *iq, size_t nbytes, rd_packet *out, int cap, int *n) {
+    if (!h || !iq || !n) return fail(RD_ERR_ARG, "null argument");
+    const size_t want = (size_t)h->NS * 2 * (size_t)h->dc.B;
+    if (nbytes != want) return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu bytes, expected %zu", nbytes, want);
+    if (h->cplx_mode) return fail(RD_ERR_STATE, "handle is in complex mode: reset() first");
+    return demod_blocks(h, iq, 0, out, cap, n);
+}
+
+extern "C" int rd_copy_discriminated_stream(rd_demod *h, int stream, double *out, size_t n);
 extern "C" int rd_copy_discriminated(rd_demod *h, double *out, size_t n) {
+    return rd_copy_discriminated_stream(h, 0, out, n);
+}
+
+extern "C" int rd_copy_discriminated_stream(rd_demod *h, int stream, double *out, size_t n) {
     if (!h || !out) return fail(RD_ERR_ARG, "null argument");
+    if (stream < 0 || stream >= h->NS) return fail(RD_ERR_ARG, "stream out of range");
     const size_t B = (size_t)h->dc.B;
     if (n != 2 * B) return fail(RD_ERR_ARG, "discriminated has %zu elements", 2 * B);
     if (h->seen == 0) {  // py:134 zeros
@@ -834,7 +866,7 @@ extern "C" int rd_copy_discriminated(rd_demod *h, double *out, size_t n) {
         return RD_OK;
     }
     // discriminated = d over [-B, B) relative to the newest block (py:156,162)
-    if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), 0, -(long)B, 2 * (long)B, h->d_tmp, nullptr);
+    if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), stream, -(long)B, 2 * (long)B, h->d_tmp, nullptr);
     else rd_launch_cplx_disc(demod_clayout(h, h->seen - 1), -(long)B, 2 * (long)B, h->d_tmp, nullptr);
     HIPCHK(hipGetLastError());
     int rc = copy_d2h(h->h_tmp, h->d_tmp, n * sizeof(double), nullptr);  // pinned: no staging, polling wait

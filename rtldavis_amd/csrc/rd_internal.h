@@ -74,7 +74,8 @@ void rd_launch_disc(const rd_layout &lay, int stream, long t0, long n, double *o
 void rd_launch_filtered(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
 // window <- (window >> shift_bits) with `block` (n_block_bits) appended at the top; window has n_win_bits
 void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_win_bits, const uint32_t *block,
-                             long n_block_bits, hipStream_t st);
+                             long n_block_bits, int n_streams, size_t win_stride, size_t block_stride,
+                             hipStream_t st);
 
 // complex128 input path (py:144-150): raw ring of interleaved doubles
 struct rd_cplx_layout {

@@ -950,11 +950,14 @@ void rd_launch_filtered(const rd_layout &lay, int stream, long t0, long n, doubl
 // i.e. np.roll(quantized, -B) followed by writing the newest block at the end (py:157,163-166)
 // ------------------------------------------------------------------------------------------
 __global__ void k_window_update(uint32_t *out, const uint32_t *in, long n_win_bits, const uint32_t *block,
-                                long n_block_bits) {
+                                long n_block_bits, size_t win_stride, size_t block_stride) {
     const long nw = (n_win_bits + 31) / 32;
     const long nbw = (n_block_bits + 31) / 32;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw) return;
+    out += (size_t)blockIdx.y * win_stride;  // one stream per grid row
+    in += (size_t)blockIdx.y * win_stride;
+    block += (size_t)blockIdx.y * block_stride;
     const long keep = n_win_bits - n_block_bits;  // bits [0, keep) come from the old window
     const long o = 32 * i;
     const uint32_t oldv = rd_bits32_at(in, nw, o + n_block_bits);
@@ -970,10 +973,11 @@ __global__ void k_window_update(uint32_t *out, const uint32_t *in, long n_win_bi
 }
 
 void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_win_bits, const uint32_t *block,
-                             long n_block_bits, hipStream_t st) {
+                             long n_block_bits, int n_streams, size_t win_stride, size_t block_stride,
+                             hipStream_t st) {
     const long nw = (n_win_bits + 31) / 32;
-    hipLaunchKernelGGL(k_window_update, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, win_out, win_in,
-                       n_win_bits, block, n_block_bits);
+    hipLaunchKernelGGL(k_window_update, dim3((unsigned)((nw + 255) / 256), (unsigned)n_streams), dim3(256), 0, st,
+                       win_out, win_in, n_win_bits, block, n_block_bits, win_stride, block_stride);
 }
 
 // ------------------------------------------------------------------------------------------

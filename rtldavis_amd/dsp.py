@@ -206,6 +206,54 @@ class Demodulator:
         return search(self.quantized, self.cfg)
 
 
+class MultiDemodulator:
+    """Several Demodulators in lock step on one GPU: one block per stream per call, all streams
+    in one set of kernel launches (one per SDR / hop channel).  Each stream
+    behaves exactly like its own ``Demodulator`` (dsp.py:128-253)."""
+
+    def __init__(self, cfg: PacketConfig, n_streams: int) -> None:
+        self.cfg = cfg
+        self.n_streams = int(n_streams)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rd_create_multi(C.byref(cfg._c()), self.n_streams, C.byref(self._h)))
+        self._cap = 64 * self.n_streams
+        self._recs = (_lib.RdPacket * self._cap)()
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().rd_destroy(self._h)
+        except Exception:
+            pass
+
+    def demodulate(self, blocks: np.ndarray) -> List[List[Packet]]:
+        """blocks: uint8 [n_streams, 2*block_size].  Returns one ``List[Packet]`` per stream."""
+        a = np.ascontiguousarray(blocks, dtype=np.uint8)
+        if a.size != self.n_streams * 2 * self.cfg.block_size:
+            logger.error(f"Incompatible array sizes: blocks.size={a.size}")
+            raise ValueError("Incompatible array sizes")
+        n = C.c_int(0)
+        rc = _lib.lib().rd_demod_blocks(self._h, a.ctypes.data, a.size, self._recs, self._cap, C.byref(n))
+        if rc == _lib.RD_ERR_CAPACITY:
+            raise BufferError(_lib.last_error())
+        _lib.check(rc)
+        out: List[List[Packet]] = [[] for _ in range(self.n_streams)]
+        for i in range(n.value):
+            r = self._recs[i]
+            data = np.frombuffer(bytes(r.data[: r.nbytes]), dtype=np.uint8)
+            out[r.stream].append(Packet(int(r.index), data, float(r.rssi), float(r.snr)))
+        return out
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib().rd_reset(self._h))
+
+    def discriminated(self, stream: int) -> np.ndarray:
+        """``Demodulator.discriminated`` of one stream (read by protocol.py:307-309)."""
+        out = np.empty(2 * self.cfg.block_size, dtype=np.float64)
+        _lib.check(_lib.lib().rd_copy_discriminated_stream(self._h, int(stream), out.ctypes.data, out.size))
+        return out
+
+
 def search(quantized: np.ndarray, cfg: PacketConfig) -> List[int]:
     """Preamble search over a 0/1-per-byte buffer in the reference's order (dsp.py:171-188,
     dsp/dsp.go:105-131)."""

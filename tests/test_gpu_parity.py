@@ -365,6 +365,35 @@ def test_mixed_uint8_then_complex_keeps_history(dsp):
     assert_calls_equal(calls, g["calls"])
 
 
+def test_multi_demodulator_lock_step(dsp, golden_streams):
+    """Five receivers fed block by block in one handle == five independent Demodulators."""
+    import math
+    seeds = [0, 1, 2, 3, 17]
+    raws = synth.synth_streams(seeds)
+    cfg = prod_cfg(dsp)
+    md = dsp.MultiDemodulator(cfg, len(seeds))
+    per = [[] for _ in seeds]
+    freq = {}
+    for b in range(synth.BLOCKS_PER_STREAM):
+        out = md.demodulate(raws[:, 2 * 8192 * b: 2 * 8192 * (b + 1)])
+        for i, pk in enumerate(out):
+            per[i].append(pk)
+            want = golden_streams[str(seeds[i])]["parse"].get(str(b))
+            if want:
+                d = md.discriminated(i)
+                idx = want[0]["index"]
+                mean = np.mean(d[idx: idx + cfg.preamble_length])
+                freq[i] = (-int((mean * float(cfg.sample_rate)) / (2 * math.pi)), want[0]["freq_err"])
+    for i, seed in enumerate(seeds):
+        assert_calls_equal(per[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+        assert freq[i][0] == freq[i][1]
+    md.reset()
+    out = md.demodulate(raws[:, : 2 * 8192])
+    assert [len(x) for x in out] == [len(per[i][0]) for i in range(len(seeds))]
+    with pytest.raises(ValueError, match="Incompatible array sizes"):
+        md.demodulate(raws[:2, : 2 * 8192])
+
+
 def test_startup_signed_zero_quadrants(dsp):
     g = load_json("startup_quadrants.json")
     cfg = prod_cfg(dsp, block_size=512)
