@@ -89,9 +89,8 @@ struct rd_run_result {
 RD_HD uint32_t rd_guard_mask(const rd_run_result &r);
 
 // Signs of rot = j^p applied to (I, Q):  p=0 ( I, Q)  p=1 (-Q, I)  p=2 (-I,-Q)  p=3 ( Q,-I).
-// With w = (I,Q) for even p and (Q,I) for odd p, y = (sr*w.x, si*w.y):
-RD_HD float rd_sr(int p) { return (p == 1 || p == 2) ? -1.0f : 1.0f; }
-RD_HD float rd_si(int p) { return (p == 2 || p == 3) ? -1.0f : 1.0f; }
+// With w = (I,Q) for even p and (Q,I) for odd p, y = (sr*w.x, si*w.y) with sr = -1 for
+// p in {1,2} and si = -1 for p in {2,3} (RD_NX / RD_NY in rd_fir_out).
 
 // Fast fp32 evaluation of one run.  `win` holds the raw bytes of samples t0-10 .. t0+30
 // (2*RD_WIN bytes, I then Q); t0 % 4 == 0 in absolute stream time.  Fully unrolled by the
@@ -368,14 +367,6 @@ RD_HD rd_i2 rd_sample_int(const rd_stream_view &v, long n) {
     }
     const uint8_t *p = v.base + 2 * n;
     return rd_rot_int(p[0], p[1], (int)(n & 3));
-}
-
-// Exact FIR output f[t] (uses y[t-9 .. t-1]); f[t] for t < valid_from is 0 (py:133 zeros).
-RD_HD rd_i2 rd_f_int(const rd_stream_view &v, long t) {
-    rd_i2 y[9];
-#pragma unroll
-    for (int m = 0; m < 9; m++) y[m] = rd_sample_int(v, t - 9 + m);
-    return rd_fir_int(y);
 }
 
 // The same decision through float64: U and taps*1e12 are integers below 2^53, so the FIR sums
