@@ -10,7 +10,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _lib
-from .dsp import Packet, PacketConfig
+from .dsp import Packet, PacketConfig, _cfg_struct
 
 
 RD_PACKET_DTYPE = np.dtype([("stream", "<i4"), ("call", "<i4"), ("index", "<i4"), ("nbytes", "<i4"),
@@ -33,7 +33,7 @@ class BatchDemodulator:
         self._b = C.c_void_p()
         if device is not None:
             _lib.check(_lib.lib().rd_set_device(int(device)))
-        _lib.check(_lib.lib().rd_batch_create(C.byref(cfg._c()), self.n_streams, self.n_blocks, C.byref(self._b)))
+        _lib.check(_lib.lib().rd_batch_create(C.byref(_cfg_struct(cfg)), self.n_streams, self.n_blocks, C.byref(self._b)))
         self._cap = 0
         self._recs = None
 

@@ -116,6 +116,12 @@ class PacketConfig:
                                 self.preamble, self.block_size)
 
 
+def _cfg_struct(cfg) -> _lib.RdConfig:
+    """rd_config from any PacketConfig-like object (ours or the reference's dsp.PacketConfig)."""
+    return _lib.make_config(cfg.bit_rate, cfg.symbol_length, cfg.preamble_symbols, cfg.packet_symbols,
+                            cfg.preamble, cfg.block_size)
+
+
 def _packets_from(recs, n: int) -> List[Packet]:
     out = []
     for i in range(n):
@@ -137,7 +143,7 @@ class Demodulator:
         self.cfg = cfg
         self._h = C.c_void_p()
         self._pid = os.getpid()
-        _lib.check(_lib.lib().rd_create(C.byref(cfg._c()), C.byref(self._h)))  # host state only
+        _lib.check(_lib.lib().rd_create(C.byref(_cfg_struct(cfg)), C.byref(self._h)))  # host state only
         self._cap = 64
         self._recs = (_lib.RdPacket * self._cap)()
         self.byte_to_cmplx = ByteToCmplxLUT()
@@ -215,7 +221,7 @@ class MultiDemodulator:
         self.cfg = cfg
         self.n_streams = int(n_streams)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().rd_create_multi(C.byref(cfg._c()), self.n_streams, C.byref(self._h)))
+        _lib.check(_lib.lib().rd_create_multi(C.byref(_cfg_struct(cfg)), self.n_streams, C.byref(self._h)))
         self._cap = 64 * self.n_streams
         self._recs = (_lib.RdPacket * self._cap)()
 
@@ -260,5 +266,5 @@ def search(quantized: np.ndarray, cfg: PacketConfig) -> List[int]:
     q = np.ascontiguousarray(quantized, dtype=np.uint8)
     idx = np.empty(max(q.size, 1), dtype=np.int32)
     n = C.c_int(0)
-    _lib.check(_lib.lib().rd_search(C.byref(cfg._c()), q.ctypes.data, q.size, idx.ctypes.data, idx.size, C.byref(n)))
+    _lib.check(_lib.lib().rd_search(C.byref(_cfg_struct(cfg)), q.ctypes.data, q.size, idx.ctypes.data, idx.size, C.byref(n)))
     return [int(v) for v in idx[: n.value]]
