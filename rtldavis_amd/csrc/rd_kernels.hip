@@ -154,7 +154,14 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
         const uint32_t run = ti * 64 + lane;
         const uint32_t t0 = run * RD_RUN;
         uint32_t gmask = 0;  // groups of 8 samples inside the guard band
-        if (t0 < lay.n_samples) {
+        // only a stream's last tile can be ragged (wave-uniform test): everywhere else the whole
+        // run is valid and none of the tail masking below is executed
+        const bool ragged = (ti + 1 == tiles_per_stream) && (lay.n_samples % RD_TILE_SAMPLES) != 0;
+        if (!ragged) {
+            st_word = r.word;
+            st_ptr = &lay.bits[(size_t)s * lay.bits_stride + run];
+            gmask = (run == 0 && !lay.hist_mode) ? 0xFu : rd_guard_mask(r);
+        } else if (t0 < lay.n_samples) {
             uint32_t word = r.word;
             const uint32_t left = lay.n_samples - t0;
             if (left < RD_RUN) word &= (1u << left) - 1u;
