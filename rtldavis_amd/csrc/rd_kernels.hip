@@ -70,10 +70,14 @@ __device__ __forceinline__ void rd_issue_tile_loads(const rd_layout &lay, uint32
                                                     int lane) {
     const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
     const int perm = 4 * (lane & 15) + (lane >> 4);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024 + perm * 16),
-                                         (__attribute__((address_space(3))) void *)(my + 32 + j * 1024), 16, 0, 0);
+    // the instruction offset advances the global and the LDS address alike: one address pair,
+    // four immediates
+    const __attribute__((address_space(1))) void *g0 = (const __attribute__((address_space(1))) void *)(src + perm * 16);
+    __attribute__((address_space(3))) void *l0 = (__attribute__((address_space(3))) void *)(my + 32);
+    __builtin_amdgcn_global_load_lds(g0, l0, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g0, l0, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(g0, l0, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(g0, l0, 16, 3072, 0);
     // halo: the 32 bytes before the tile (previous tile, or the caller's history bytes).
     // With zero history there is nothing to read: run 0 is always re-evaluated exactly.
     const bool has_halo = (ti > 0) || lay.hist_mode;
