@@ -10,8 +10,12 @@
  * Conventions: plain pointers and sizes only; every function returns RD_OK (0) or a
  * negative rd_status; outputs are caller-allocated; no callbacks; no global state other
  * than the per-process HIP context, which is created lazily by the first call that
- * needs the device (never by rd_create / rd_batch_create with defer_device != 0), so
- * a handle may be created before fork() (py worker model: __main__.py:277, worker.py:29).
+ * needs the device (never by rd_create / rd_create_multi / rd_batch_create), so a handle
+ * may be created before fork() (py worker model: __main__.py:277, worker.py:29); a process
+ * forked AFTER the device was used gets RD_ERR_DEVICE instead of undefined behaviour.
+ * A handle is used by one thread at a time (like a reference Demodulator); different handles
+ * are independent.  There is no CPU fallback: without a usable HIP device every entry point
+ * that computes returns RD_ERR_DEVICE.
  * rd_last_error() returns a thread-local, human-readable message for the last failure.
  */
 #ifndef RTLDAVIS_HIP_H
