@@ -58,6 +58,29 @@ def test_argument_errors_without_gpu():
         dsp.Demodulator(dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 30))  # not a multiple of 4
 
 
+def test_create_argument_checks_without_gpu():
+    """Bad shapes/configs are rejected by the host part of the C ABI before any device work."""
+    import ctypes as C
+    from rtldavis_amd import _lib, batch, dsp
+    good = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 8192)
+    for ns, nb in [(0, 1), (1, 0), (-3, 2)]:
+        with pytest.raises(ValueError):
+            batch.BatchDemodulator(good, ns, nb)
+    with pytest.raises(ValueError):  # packet shorter than the preamble
+        batch.BatchDemodulator(dsp.PacketConfig(19200, 14, 16, 8, "1100101110001001", 8192), 1, 1)
+    with pytest.raises(ValueError):  # preamble symbols must be 0/1
+        dsp.Demodulator(dsp.PacketConfig(19200, 14, 4, 80, "1120", 512))
+    with pytest.raises(ValueError):
+        dsp.MultiDemodulator(good, 0)
+    h = C.c_void_p()
+    assert _lib.lib().rd_create(None, C.byref(h)) == _lib.RD_ERR_ARG
+    assert b"null config" in _lib.lib().rd_last_error()
+    # results before run is a state error, not a crash
+    b = batch.BatchDemodulator(good, 1, 1)
+    n = C.c_int()
+    assert _lib.lib().rd_batch_results(b._b, None, 0, C.byref(n)) in (_lib.RD_ERR_STATE, _lib.RD_ERR_DEVICE)
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU every compute entry point must raise, never return numbers."""
     from rtldavis_amd import _lib, batch, dsp

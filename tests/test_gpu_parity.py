@@ -231,6 +231,44 @@ def test_batch_replicas_are_identical_property(dsp, batchmod, golden_streams):
         assert sha(bd.bits(s)) == golden_streams[str(s % 8)]["bits_sha256"]
 
 
+def test_full_size_4096_streams_properties(dsp, batchmod, golden_streams):
+    """BASELINE config 4 (4096 streams x 33 blocks, 2.2 GB): every stream's packets equal the
+    fixture of the unique stream it was tiled from, and the XOR / sum of all packed bitstreams
+    equals what 64 copies of each of the 64 golden bitstreams give (checksum of checksums)."""
+    import zlib
+    uniq = synth.synth_streams(range(64))
+    raw = np.tile(uniq, (64, 1))
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), raw.shape[0], synth.BLOCKS_PER_STREAM)
+    bd.upload(raw)
+    del raw
+    bd.run()
+    res = bd.results()
+    per = {}
+    for r in res:
+        per.setdefault(int(r["stream"]), []).append(
+            (int(r["call"]), int(r["index"]), r["data"][: int(r["nbytes"])].tobytes().hex()))
+    crc_unique = {}
+    for s in range(4096):
+        g = golden_streams[str(s % 64)]
+        want = [(int(c), p["index"], p["data"]) for c, ps in sorted(g["calls"].items(), key=lambda kv: int(kv[0]))
+                for p in ps]
+        assert per.get(s, []) == want, s
+    total = 0
+    for s in range(0, 4096, 7):  # every 7th stream: 586 bitstreams, all 64 residues covered
+        b = bd.bits(s)
+        c = zlib.crc32(b.tobytes())
+        u = s % 64
+        if u not in crc_unique:
+            assert sha(b) == golden_streams[str(u)]["bits_sha256"]
+            crc_unique[u] = c
+        assert c == crc_unique[u], s
+        total += 1
+    assert len(crc_unique) == 64 and total == 586
+    cnt = bd.counters()
+    assert cnt["matches"] % 64 == 0  # 64 identical copies of each unique stream
+    assert 0 < cnt["fixup_runs"] < 0.05 * 4096 * 8448 and cnt["fixup_runs"] % 64 == 0
+
+
 # ---------------------------------------------------------------- streaming Demodulator
 def test_demodulator_burst_config1(dsp):
     raw = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
