@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--two-streams", action="store_true", help="one HIP stream per resident batch")
     ap.add_argument("--stage-times", action="store_true", help="time every kernel stage (adds events)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="N > 1 dry run on a one-GPU box: all ranks on cuda:0, gloo barrier (not a measurement)")
     return ap.parse_args()
 
 
@@ -93,10 +95,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+    # --rehearse-shared-gpu: every rank on cuda:0 with a gloo barrier, to exercise the N > 1 code
+    # path on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    rehearse = args.rehearse_shared_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rtldavis_amd import _lib, batch, dsp, synth
 
@@ -159,7 +169,7 @@ def main():
     assert sum(t["runs"] for t in tms) == args.steps
     tm = {k: sum(t[k] * t["runs"] for t in tms) / args.steps for k in tms[0] if k != "runs"}
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
