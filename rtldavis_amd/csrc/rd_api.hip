@@ -152,8 +152,12 @@ static int make_devcfg(const rd_config *c, rd_devcfg *d) {
 static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector<rd_packet> &out) {
     out.clear();
     if (n == 0) return;
-    std::vector<uint32_t> idx(n);
-    for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+    std::vector<uint32_t> idx;
+    idx.reserve(n);
+    for (size_t i = 0; i < n; i++)
+        if (recs[i].stream >= 0) idx.push_back((uint32_t)i);  // stream < 0: match reported by no call
+    n = idx.size();
+    if (n == 0) return;
     auto less = [&](uint32_t ia, uint32_t ib) {
         const rd_packet &a = recs[ia], &b = recs[ib];
         if (a.stream != b.stream) return a.stream < b.stream;
@@ -168,9 +172,10 @@ static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector
         // field widths
         uint32_t max_stream = 0, max_call = 0, max_index = 0;
         for (size_t i = 0; i < n; i++) {
-            max_stream = std::max(max_stream, (uint32_t)recs[i].stream);
-            max_call = std::max(max_call, (uint32_t)recs[i].call);
-            max_index = std::max(max_index, (uint32_t)recs[i].index);
+            const rd_packet &r = recs[idx[i]];
+            max_stream = std::max(max_stream, (uint32_t)r.stream);
+            max_call = std::max(max_call, (uint32_t)r.call);
+            max_index = std::max(max_index, (uint32_t)r.index);
         }
         auto bits_for = [](uint32_t v) { int b = 1; while (b < 32 && (v >> b)) b++; return b; };
         const int bi = bits_for(max_index), bp = bits_for((uint32_t)(S - 1)), bc = bits_for(max_call),
@@ -179,7 +184,7 @@ static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector
             std::vector<uint64_t> key(n), ktmp(n);
             std::vector<uint32_t> itmp(n);
             for (size_t i = 0; i < n; i++) {
-                const rd_packet &r = recs[i];
+                const rd_packet &r = recs[idx[i]];
                 key[i] = ((((uint64_t)(uint32_t)r.stream << bc | (uint32_t)r.call) << bp | (uint32_t)(r.index % S)) << bi) |
                          (uint32_t)r.index;
             }
@@ -226,8 +231,8 @@ struct rd_batch {
     size_t iq_bytes = 0;
     uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
     rd_match *d_matches = nullptr;
-    rd_packet *d_recs = nullptr;
-    rd_dedupe_ws ws = {};
+    rd_packet *d_recs = nullptr;     // rec_cap = 2 * match_cap entries (layout: rd_launch_slice)
+    int cnt_set = 0;                 // d_cnt holds two counter sets; a run's fixup kernel clears the other one
     bool parse = false;              // Parser.parse front half on the device (rd_batch_set_parse)
     rd_parsed *d_parsed = nullptr;   // rec_cap entries
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
@@ -283,24 +288,7 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
     return RD_OK;
 }
 
-static uint32_t pow2_at_least(uint64_t v) {
-    uint32_t p = 1024;
-    while (p < v && p < (1u << 31)) p <<= 1;
-    return p;
-}
-
-static void free_dedupe_ws(rd_dedupe_ws &ws) {
-    hipFree(ws.table); hipFree(ws.slot_of); hipFree(ws.final_recs);
-    ws = rd_dedupe_ws{};
-}
-
-static int alloc_dedupe_ws(rd_dedupe_ws &ws, uint32_t rec_cap) {
-    ws.slots = pow2_at_least(2ull * rec_cap);
-    HIPCHK(hipMalloc(&ws.table, (size_t)ws.slots * 16));
-    HIPCHK(hipMalloc(&ws.slot_of, (size_t)rec_cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&ws.final_recs, (size_t)rec_cap * sizeof(rd_packet)));
-    return RD_OK;
-}
+static uint32_t *batch_cnt(const rd_batch *b) { return b->d_cnt + (size_t)b->cnt_set * RD_CNT_SLOTS; }
 
 static int batch_alloc(rd_batch *b) {
     if (b->dev_ready) return RD_OK;
@@ -317,10 +305,10 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));
     HIPCHK(hipMalloc(&b->d_bits, runs * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_fix, (size_t)b->fix_cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b->d_cnt, 2 * RD_CNT_SLOTS * sizeof(uint32_t)));
+    HIPCHK(hipMemset(b->d_cnt, 0, 2 * RD_CNT_SLOTS * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
-    { int rc2 = alloc_dedupe_ws(b->ws, b->rec_cap); if (rc2) return rc2; }
     HIPCHK(hipHostMalloc((void **)&b->h_cnt_pin, RD_CNT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     b->rec_pin_cap = b->rec_cap;
@@ -336,7 +324,6 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
     if (b->dev_ready && g_hip_pid == getpid()) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs);
-        free_dedupe_ws(b->ws);
         hipFree(b->d_parsed);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
@@ -372,13 +359,13 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     const rd_layout lay = batch_layout(b);
     const long B = b->dc.B, L = b->dc.L;
     rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
-                     b->dc, b->d_matches, b->match_cap, b->d_cnt, st);
+                     b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
     if (b->timing && b->timing_detail) hipEventRecord(b->ev[3], st);
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
-                    b->d_recs, b->rec_cap, b->ws, b->d_cnt, st);
+                    b->d_recs, batch_cnt(b), st);
     if (b->parse) {
         if (!b->d_parsed) hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed));
-        if (b->d_parsed) rd_launch_parse(lay, b->dc, b->ws.final_recs, b->rec_cap, b->d_parsed, b->d_cnt, st);
+        if (b->d_parsed) rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
     }
     if (b->timing) hipEventRecord(b->ev[4], st);
     // results come back with the run: counters plus as many records as the last run produced
@@ -387,10 +374,10 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     // not wait for them.
     hipEventRecord(b->kdone, st);
     hipStreamWaitEvent(b->copy_stream, b->kdone, 0);
-    hipMemcpyAsync(b->h_cnt_pin, b->d_cnt, RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
-    const uint32_t spec = std::min(b->rec_cap, b->spec_recs);
+    hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
+    const uint32_t spec = std::min(b->match_cap, b->spec_recs);
     if (spec)
-        hipMemcpyAsync(b->h_recs_pin, b->ws.final_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
+        hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
                        b->copy_stream);
     hipEventRecord(b->done, b->copy_stream);
 }
@@ -402,8 +389,10 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     b->stream = st;
     const rd_layout lay = batch_layout(b);
-    if (b->ran) HIPCHK(hipStreamWaitEvent(st, b->done, 0));  // the previous run's readback of d_cnt / d_recs
-    HIPCHK(hipMemsetAsync(b->d_cnt, 0, RD_CNT_SLOTS * sizeof(uint32_t), st));
+    if (b->ran) HIPCHK(hipStreamWaitEvent(st, b->done, 0));  // the previous run's readback of d_recs
+    // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
+    b->cnt_set ^= 1;
+    uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * RD_CNT_SLOTS;
     if (b->timing) {
         if (b->evs.size() < 5 * (b->ev_runs + 1)) {
             const size_t old = b->evs.size();
@@ -414,9 +403,9 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         b->ev_runs++;
     }
     if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
-    if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, b->d_cnt, st);
+    if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st);
     if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
-    rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, b->fast_ok ? 0 : 1, st);
+    rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
     batch_search_slice(b, st);
     HIPCHK(hipGetLastError());
@@ -438,9 +427,9 @@ static int batch_finish(rd_batch *b) {
         if (b->fast_ok && b->h_cnt[RD_CNT_FIX] > b->fix_cap) {
             // guard list overflowed (degenerate input): re-evaluate every run exactly
             const rd_layout lay = batch_layout(b);
-            rd_launch_fixup(lay, b->d_fix, b->fix_cap, b->d_cnt, 1, st);
+            rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
             uint32_t cap = b->fix_cap;  // mark handled
-            HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
             b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
             redo_search = true;
         } else if (attempt == 0) {
@@ -448,13 +437,11 @@ static int batch_finish(rd_batch *b) {
         }
         if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
             hipFree(b->d_matches); hipFree(b->d_recs); hipHostFree(b->h_recs_pin);
-            free_dedupe_ws(b->ws);
             hipFree(b->d_parsed); b->d_parsed = nullptr;
             b->match_cap = b->h_cnt[RD_CNT_MATCH] + b->h_cnt[RD_CNT_MATCH] / 4 + 1024;
             b->rec_cap = 2 * b->match_cap;
             HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
             HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
-            { int rc2 = alloc_dedupe_ws(b->ws, b->rec_cap); if (rc2) return rc2; }
             HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
             b->rec_pin_cap = b->rec_cap;
             redo_search = true;
@@ -463,8 +450,8 @@ static int batch_finish(rd_batch *b) {
             b->last_match = b->h_cnt[RD_CNT_MATCH];
             return RD_OK;
         }
-        const uint32_t zero[4] = {0, 0, 0, 0};  // matches, raw records, final records, parsed
-        HIPCHK(hipMemcpyAsync(b->d_cnt + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
+        const uint32_t zero[4] = {0, 0, 0, 0};  // matches, boundary records, (unused), parsed
+        HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
         batch_search_slice(b, st);
     }
     return fail(RD_ERR_DEVICE, "result lists kept overflowing");
@@ -476,14 +463,21 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     int rc = batch_finish(b);
     if (rc) return rc;
     const double t1 = now_ms();
-    const uint32_t nrec = std::min(b->h_cnt[RD_CNT_FINAL], b->rec_cap);  // after the on-device dedupe
-    const uint32_t have = std::min(b->rec_cap, b->spec_recs);
-    if (nrec > have) {  // more records than were copied back with the run: fetch the rest
-        rc = copy_d2h(b->h_recs_pin + have, b->ws.final_recs + have, (size_t)(nrec - have) * sizeof(rd_packet),
-                      b->stream);
+    // one record per match, plus the second records of block-boundary positions (kept apart on
+    // the device, appended here)
+    const uint32_t nprim = std::min(b->h_cnt[RD_CNT_MATCH], b->match_cap);
+    const uint32_t nextra = std::min(b->h_cnt[RD_CNT_REC], b->match_cap);
+    const uint32_t have = std::min(b->match_cap, b->spec_recs);
+    if (nprim > have) {  // more records than were copied back with the run: fetch the rest
+        rc = copy_d2h(b->h_recs_pin + have, b->d_recs + have, (size_t)(nprim - have) * sizeof(rd_packet), b->stream);
         if (rc) return rc;
     }
-    b->spec_recs = std::max<uint32_t>(1024, nrec + nrec / 4);
+    if (nextra) {
+        rc = copy_d2h(b->h_recs_pin + nprim, b->d_recs + b->match_cap, (size_t)nextra * sizeof(rd_packet), b->stream);
+        if (rc) return rc;
+    }
+    const uint32_t nrec = nprim + nextra;
+    b->spec_recs = std::max<uint32_t>(1024, nprim + nprim / 4);
     std::vector<rd_packet> recs;
     const double t2 = now_ms();
     order_and_dedupe(b->h_recs_pin, nrec, b->dc.S, recs);
@@ -549,11 +543,22 @@ extern "C" int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n) {
         if (px != py) return px < py;
         return x.index < y.index;
     });
-    *n = (int)np;
-    if ((int)np > cap) return fail(RD_ERR_CAPACITY, "need room for %u messages", np);
-    if (np) {
+    // a call reports a byte string once (py:203-205, first occurrence in _slice's order): messages
+    // with equal bytes come from packets with equal bytes (the sync word is the matched preamble)
+    size_t kept = 0, group = 0;
+    for (size_t i = 0; i < recs.size(); i++) {
+        const rd_parsed &r = recs[i];
+        if (kept == 0 || r.stream != recs[kept - 1].stream || r.call != recs[kept - 1].call) group = kept;
+        bool dup = false;
+        for (size_t k = group; k < kept && !dup; k++)
+            dup = recs[k].nbytes == r.nbytes && memcmp(recs[k].data, r.data, sizeof r.data) == 0;
+        if (!dup) recs[kept++] = r;
+    }
+    *n = (int)kept;
+    if ((int)kept > cap) return fail(RD_ERR_CAPACITY, "need room for %zu messages", kept);
+    if (kept) {
         if (!out) return fail(RD_ERR_ARG, "null out");
-        memcpy(out, recs.data(), (size_t)np * sizeof(rd_parsed));
+        memcpy(out, recs.data(), kept * sizeof(rd_parsed));
     }
     return RD_OK;
 }
@@ -626,7 +631,6 @@ struct rd_demod {
     int cur_win = 0;
     rd_match *d_matches = nullptr;
     rd_packet *d_recs = nullptr;
-    rd_dedupe_ws ws = {};
     double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
     double *h_tmp = nullptr;        // pinned mirror of d_tmp (state accessors)
     uint8_t *h_in = nullptr;        // pinned staging of one input block
@@ -678,7 +682,6 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
     HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(rd_packet)));
-    { int rc2 = alloc_dedupe_ws(h->ws, h->rec_cap); if (rc2) return rc2; }
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&h->h_in, std::max(16 * B, NS * 2 * B), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_tmp, 2 * (2 * B + 2) * sizeof(double), hipHostMallocDefault));
@@ -694,7 +697,6 @@ extern "C" void rd_destroy(rd_demod *h) {
         hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_stage); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_recs); hipFree(h->d_tmp);
-        free_dedupe_ws(h->ws);
         hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs); hipHostFree(h->h_tmp);
     }
     delete h;
@@ -792,7 +794,7 @@ static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_pac
     if (!h->cplx_mode) {
         const rd_layout lay = demod_layout(h, seen_before);
         if (h->fast_ok) rd_launch_demod(lay, h->d_fix, h->fix_cap, h->d_cnt, st);
-        rd_launch_fixup(lay, h->d_fix, h->fix_cap, h->d_cnt, h->fast_ok ? 0 : 1, st);
+        rd_launch_fixup(lay, h->d_fix, h->fix_cap, h->d_cnt, h->fast_ok ? 0 : 1, nullptr, st);
     } else {
         rd_launch_cplx_bits(demod_clayout(h, seen_before), h->d_blockbits, st);
     }
@@ -804,21 +806,21 @@ static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_pac
     rd_launch_search(h->d_win[nw], lw, h->NS, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
     if (!h->cplx_mode)
         rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], lw, (long)L, h->dc, h->d_matches, h->match_cap, 0,
-                        0, (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
+                        0, (int)seen_before, h->d_recs, h->d_cnt, st);
     else
         rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
-                             (int)seen_before, h->d_recs, h->rec_cap, h->ws, h->d_cnt, st);
+                             (int)seen_before, h->d_recs, h->d_cnt, st);
     HIPCHK(hipGetLastError());
     // counters and the first records come back with the block; polling wait (see wait_stream)
     const uint32_t spec = std::min<uint32_t>(h->rec_cap, 32 * (uint32_t)NS);
     HIPCHK(hipMemcpyAsync(h->h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h->h_recs, h->ws.final_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
     rc = wait_stream(st);
     if (rc) return rc;
     h->seen = seen_before + 1;
-    const uint32_t nrec = std::min(h->h_cnt[RD_CNT_FINAL], h->rec_cap);
+    const uint32_t nrec = std::min(h->h_cnt[RD_CNT_MATCH], h->match_cap);  // one record per match (no call overlap here)
     if (nrec > spec) {
-        rc = copy_d2h(h->h_recs + spec, h->ws.final_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
+        rc = copy_d2h(h->h_recs + spec, h->d_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
         if (rc) return rc;
     }
     std::vector<rd_packet> recs;

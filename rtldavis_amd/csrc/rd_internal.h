@@ -6,7 +6,9 @@
 #include "../../include/rtldavis_hip.h"
 
 // counters[] slots (device uint32)
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_FINAL = 3, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
+// FIX: flagged runs; MATCH: preamble matches (= primary records); REC: second records of
+// block-boundary positions; PARSED: CRC-valid messages
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
 
 // Geometry of the fused demod kernel
 #define RD_TILE_SAMPLES 2048  // 64 lanes x 32 samples: one wave iteration
@@ -37,36 +39,30 @@ struct rd_match {
     int32_t pos;  // bit-array coordinate of the first preamble sample
 };
 
-// Workspace of the on-device per-call dedupe (py:203-205: first occurrence of a byte string
-// wins inside one call): an open-addressing table keyed by (stream, call, data).
-struct rd_dedupe_ws {
-    uint64_t *table;     // 2 * slots u64: [2s] = owner record (all ones = empty), [2s+1] = min order key
-    uint32_t slots;      // power of two, >= 2 * rec_cap
-    uint32_t *slot_of;   // rec_cap entries: table slot of each raw record
-    rd_packet *final_recs;  // rec_cap entries: surviving records, compacted (RD_CNT_FINAL of them)
-};
-
 // --- launches (all asynchronous on `st`) ---
 void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
+// zero_next (may be null): RD_CNT_SLOTS counters to clear for the handle's next run.
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
-                     hipStream_t st);
+                     uint32_t *zero_next, hipStream_t st);
 // Search positions p in [p_lo, p_hi] of every stream's bit array (bits outside [0, n_bits) are 0).
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
                       hipStream_t st);
-// Slice + RSSI/SNR.  batch_mode = 1: position = absolute sample, calls derived from it
-// (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
+// Slice + RSSI/SNR, one wave per match.  batch_mode = 1: position = absolute sample, calls derived
+// from it (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
 // lay.iq points at the newest block's first sample.
-// Raw records go to `recs` (RD_CNT_REC), per-call duplicates are dropped on the device and the
-// survivors, with RSSI/SNR filled in, land compacted in ws.final_recs (RD_CNT_FINAL).
+// recs holds 2 * match_cap entries: recs[i] is match i's record (stream = -1 when no call reports
+// it); the second record of a position on a block boundary (q = B in call b and q = 0 in call
+// b+1, py:194) goes to recs[match_cap + k], k < RD_CNT_REC.  Per-call duplicates (py:203-205) are
+// left to the host, which orders the records anyway.
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st);
-// Parser.parse front half (protocol.py:290-311) over the final records of a batch run:
-// CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
-void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *final_recs, uint32_t rec_cap,
+                     rd_packet *recs, uint32_t *counters, hipStream_t st);
+// Parser.parse front half (protocol.py:290-311) over the records of a batch run (layout as
+// above): CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
+void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,
                      rd_parsed *parsed, uint32_t *counters, hipStream_t st);
 // d[t0 .. t0+n) of stream `stream` in float64
 void rd_launch_disc(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
@@ -87,8 +83,8 @@ void rd_launch_cplx_bits(const rd_cplx_layout &lay, uint32_t *bits, hipStream_t 
 void rd_launch_cplx_disc(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
 void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
-                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t rec_cap,
-                          const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st);
+                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t *counters,
+                          hipStream_t st);
 void rd_launch_lut(const uint8_t *in, double *out, size_t n_cplx, hipStream_t st);
 
 // stage kernels on device arrays (float64)

@@ -235,7 +235,10 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
 // k_fixup: exact bits for the listed runs (one lane per run).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_stream, const uint32_t *fix_list,
-                                               uint32_t fix_cap, const uint32_t *counters, int all) {
+                                               uint32_t fix_cap, const uint32_t *counters, int all,
+                                               uint32_t *zero_next) {
+    // the counters of the handle's NEXT run (double-buffered) are cleared here, saving a memset launch
+    if (zero_next && blockIdx.x == 0 && threadIdx.x < RD_CNT_SLOTS) zero_next[threadIdx.x] = 0;
     uint64_t count;
     if (all) {
         count = (uint64_t)lay.n_streams * runs_per_stream;
@@ -261,8 +264,10 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
             const uint32_t s = widx / (uint32_t)lay.bits_stride;
             const uint32_t run = widx - s * (uint32_t)lay.bits_stride;
             v.base = lay.iq + (size_t)s * lay.stream_stride;
-            // (a per-lane "lowest flagged group first" loop was tried: 25 % slower, the kernel is
-            // latency- not ALU-bound and the static loop lets the four iterations' loads overlap)
+            // Tried and measured no faster: a per-lane "lowest flagged group first" loop (25 % slower)
+            // and expanding the entries into one (word, group) item per lane through LDS (3.6x fewer
+            // instructions, same 50 us): the kernel waits on ~0.6 M scattered 64-128 B reads of the
+            // IQ stream, not on the ALU, and the static loop lets the four iterations' loads overlap.
             for (int g = 0; g < RD_GROUPS; g++) {
                 if (!((e >> g) & 1)) continue;
                 const long t0 = (long)run * RD_RUN + g * RD_GROUP;
@@ -286,14 +291,15 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
 }
 
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
-                     hipStream_t st) {
+                     uint32_t *zero_next, hipStream_t st) {
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
     if (rps == 0 || lay.n_streams == 0) return;
     uint64_t want = all ? (uint64_t)lay.n_streams * rps : fix_cap;
     uint64_t wgs = (want + 255) / 256;
     if (wgs > 256ull * 16) wgs = 256ull * 16;
     if (wgs == 0) wgs = 1;
-    hipLaunchKernelGGL(k_fixup, dim3((unsigned)wgs), dim3(256), 0, st, lay, rps, fix_list, fix_cap, counters, all);
+    hipLaunchKernelGGL(k_fixup, dim3((unsigned)wgs), dim3(256), 0, st, lay, rps, fix_list, fix_cap, counters, all,
+                       zero_next);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -318,6 +324,10 @@ __device__ __forceinline__ uint32_t rd_bits32_at(const uint32_t *w, long nwords,
 
 #define RD_SEARCH_OUT 4     // output words (32 positions each) per lane
 #define RD_MATCH_PEND 128   // staged matches per wave
+#define RD_SEARCH_WAVES 4    // waves per workgroup (16 was tried to cut the end-of-kernel atomics: no gain)
+#ifndef RD_SEARCH_UNROLL
+#define RD_SEARCH_UNROLL 2
+#endif
 
 __device__ __forceinline__ void rd_flush_matches(const rd_match *pend, uint32_t count, rd_match *matches,
                                                  uint32_t match_cap, uint32_t *counters, int lane) {
@@ -332,11 +342,11 @@ __device__ __forceinline__ void rd_flush_matches(const rd_match *pend, uint32_t 
 // S_ > 0: compile-time symbol length / preamble length (register funnel with constant
 // shifts); S_ == 0: run-time cfg.S / cfg.P (words fetched per tap).
 template <int S_, int P_, uint64_t PRE_>
-__global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
+__global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
                                                 long base, long groups_per_stream, long p_lo, long p_hi,
                                                 rd_devcfg cfg, rd_match *matches, uint32_t match_cap,
                                                 uint32_t *counters) {
-    __shared__ rd_match pend_all[4][RD_MATCH_PEND];
+    __shared__ rd_match pend_all[RD_SEARCH_WAVES][RD_MATCH_PEND];
     const int lane = threadIdx.x & 63;
     rd_match *pend = pend_all[threadIdx.x >> 6];
     uint32_t npend = 0;  // wave-uniform
@@ -344,111 +354,137 @@ __global__ __launch_bounds__(256) void k_search(const uint32_t *bits, size_t bit
     // stream / group split is scalar arithmetic
     const uint32_t wgps = (uint32_t)((groups_per_stream + 63) / 64);  // wave-groups per stream
     const uint32_t nwave_groups = (uint32_t)n_streams * wgps;
-    const uint32_t nwaves = gridDim.x * 4;
-    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    for (uint32_t wg = wave0; wg < nwave_groups; wg += nwaves) {
-        const uint32_t s = wg / wgps;
-        const long gi = (long)(wg - s * wgps) * 64 + lane;
-        uint32_t m[RD_SEARCH_OUT] = {0, 0, 0, 0};
-        long p0 = 0;
-        if (gi < groups_per_stream) {
-            p0 = base + 32L * RD_SEARCH_OUT * gi;
-            const uint32_t *w = bits + (size_t)s * bits_stride;
+    const uint32_t nwaves = gridDim.x * RD_SEARCH_WAVES;
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * RD_SEARCH_WAVES + (threadIdx.x >> 6));
+    // RD_SEARCH_UNROLL wave-groups per trip: all their loads are issued before the first is used
+    // (the kernel is a chain of load latencies, not of ALU work)
+    constexpr int NW = S_ > 0 ? ((RD_SEARCH_OUT + ((P_ > 0 ? P_ - 1 : 0) * (S_ > 0 ? S_ : 1) + 31) / 32 + 1 + 3) / 4) * 4 : 4;
+    for (uint32_t wg0 = wave0; wg0 < nwave_groups; wg0 += nwaves * RD_SEARCH_UNROLL) {
+        uint32_t r[RD_SEARCH_UNROLL][NW];
+        if constexpr (S_ > 0) {
 #pragma unroll
-            for (int o = 0; o < RD_SEARCH_OUT; o++) m[o] = 0xFFFFFFFFu;
-            if constexpr (S_ > 0) {
-                constexpr int NW = ((RD_SEARCH_OUT + ((P_ - 1) * S_ + 31) / 32 + 1 + 3) / 4) * 4;
-                const long w0 = p0 >> 5;  // multiple of 4 words: 16-byte aligned when the stream's words are
-                uint32_t r[NW];
-                if (w0 >= 0 && w0 + NW <= nwords && (((size_t)(w + w0)) & 15) == 0) {
+            for (int u = 0; u < RD_SEARCH_UNROLL; u++) {
+                const uint32_t wg = wg0 + u * nwaves;
+                if (wg >= nwave_groups) break;  // wave-uniform
+                const uint32_t s = wg / wgps;
+                const long gi = (long)(wg - s * wgps) * 64 + lane;
+                const uint32_t *w = bits + (size_t)s * bits_stride;
+                const long w0 = (base + 32L * RD_SEARCH_OUT * gi) >> 5;  // multiple of 4 words
+                if (gi < groups_per_stream && w0 >= 0 && w0 + NW <= nwords && (((size_t)(w + w0)) & 15) == 0) {
                     // interior: NW/4 coalesced 16-byte loads (lane i reads bytes 16i.. of the wave's span)
 #pragma unroll
                     for (int j = 0; j < NW / 4; j++) {
                         const uint4 v4 = *(const uint4 *)(w + w0 + 4 * j);
-                        r[4 * j] = v4.x; r[4 * j + 1] = v4.y; r[4 * j + 2] = v4.z; r[4 * j + 3] = v4.w;
+                        r[u][4 * j] = v4.x; r[u][4 * j + 1] = v4.y; r[u][4 * j + 2] = v4.z; r[u][4 * j + 3] = v4.w;
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < NW; j++) r[j] = rd_word_at(w, nwords, w0 + j);
+                    for (int j = 0; j < NW; j++) r[u][j] = gi < groups_per_stream ? rd_word_at(w, nwords, w0 + j) : 0u;
                 }
-                // compile-time preamble: all[o] = AND of the taps that must be 1, any[o] = OR of the
-                // taps that must be 0 (two at a time with v_or3_b32); match = all & ~any
-                uint32_t any[RD_SEARCH_OUT] = {0, 0, 0, 0};
-                uint32_t held[RD_SEARCH_OUT];
-                bool have_held = false;
-#pragma unroll
-                for (int k = 0; k < P_; k++) {
-                    const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
-                    const bool one = (PRE_ >> k) & 1;
-#pragma unroll
-                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
-                        const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[o + wj + 1], r[o + wj], sh) : r[o + wj];
-                        if (one) m[o] &= v;
-                        else if (have_held) any[o] = any[o] | held[o] | v;
-                        else held[o] = v;
-                    }
-                    if (!one) have_held = !have_held;
-                }
-#pragma unroll
-                for (int o = 0; o < RD_SEARCH_OUT; o++) {
-                    if (have_held) any[o] |= held[o];
-                    m[o] &= ~any[o];
-                }
-            } else {
-                for (int k = 0; k < cfg.P; k++) {
-                    const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int o = 0; o < RD_SEARCH_OUT; o++)
-                        m[o] &= rd_bits32_at(w, nwords, p0 + 32 * o + (long)k * cfg.S) ^ x;
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < RD_SEARCH_OUT; o++) {  // keep positions inside [p_lo, p_hi]
-                const long q0 = p0 + 32 * o;
-                if (q0 < p_lo) m[o] &= (p_lo - q0 >= 32) ? 0u : (0xFFFFFFFFu << (p_lo - q0));
-                if (q0 + 31 > p_hi) m[o] &= (p_hi < q0) ? 0u : (0xFFFFFFFFu >> (31 - (p_hi - q0)));
             }
         }
 #pragma unroll
-        for (int o = 0; o < RD_SEARCH_OUT; o++) {
-            uint32_t mm = m[o];
-            uint64_t any = __ballot(mm != 0);
-            while (any) {  // each round, every lane with matches left contributes its lowest one
-                const uint32_t nf = (uint32_t)__popcll(any);
-                if (npend + nf > RD_MATCH_PEND) {
-                    rd_flush_matches(pend, npend, matches, match_cap, counters, lane);
-                    npend = 0;
+        for (int u = 0; u < RD_SEARCH_UNROLL; u++) {
+            const uint32_t wg = wg0 + u * nwaves;
+            if (wg >= nwave_groups) break;  // wave-uniform
+            const uint32_t s = wg / wgps;
+            const long gi = (long)(wg - s * wgps) * 64 + lane;
+            uint32_t m[RD_SEARCH_OUT] = {0, 0, 0, 0};
+            long p0 = 0;
+            if (gi < groups_per_stream) {
+                p0 = base + 32L * RD_SEARCH_OUT * gi;
+                const uint32_t *w = bits + (size_t)s * bits_stride;
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) m[o] = 0xFFFFFFFFu;
+                if constexpr (S_ > 0) {
+                    // compile-time preamble: all[o] = AND of the taps that must be 1, any[o] = OR of
+                    // the taps that must be 0 (two at a time with v_or3_b32); match = all & ~any
+                    uint32_t any[RD_SEARCH_OUT] = {0, 0, 0, 0};
+                    uint32_t held[RD_SEARCH_OUT];
+                    bool have_held = false;
+#pragma unroll
+                    for (int k = 0; k < P_; k++) {
+                        const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
+                        const bool one = (PRE_ >> k) & 1;
+#pragma unroll
+                        for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                            const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[u][o + wj + 1], r[u][o + wj], sh) : r[u][o + wj];
+                            if (one) m[o] &= v;
+                            else if (have_held) any[o] = any[o] | held[o] | v;
+                            else held[o] = v;
+                        }
+                        if (!one) have_held = !have_held;
+                    }
+#pragma unroll
+                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                        if (have_held) any[o] |= held[o];
+                        m[o] &= ~any[o];
+                    }
+                } else {
+                    for (int k = 0; k < cfg.P; k++) {
+                        const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int o = 0; o < RD_SEARCH_OUT; o++)
+                            m[o] &= rd_bits32_at(w, nwords, p0 + 32 * o + (long)k * cfg.S) ^ x;
+                    }
                 }
-                if (mm) {
-                    const int bpos = __builtin_ctz(mm);
-                    mm &= mm - 1;
-                    rd_match e;
-                    e.stream = (int32_t)s;
-                    e.pos = (int32_t)(p0 + 32 * o + bpos);
-                    pend[npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0))] = e;
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) {  // keep positions inside [p_lo, p_hi]
+                    const long q0 = p0 + 32 * o;
+                    if (q0 < p_lo) m[o] &= (p_lo - q0 >= 32) ? 0u : (0xFFFFFFFFu << (p_lo - q0));
+                    if (q0 + 31 > p_hi) m[o] &= (p_hi < q0) ? 0u : (0xFFFFFFFFu >> (31 - (p_hi - q0)));
                 }
-                npend += nf;
-                any = __ballot(mm != 0);
+            }
+#pragma unroll
+            for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                uint32_t mm = m[o];
+                uint64_t any = __ballot(mm != 0);
+                while (any) {  // each round, every lane with matches left contributes its lowest one
+                    const uint32_t nf = (uint32_t)__popcll(any);
+                    if (npend + nf > RD_MATCH_PEND) {
+                        rd_flush_matches(pend, npend, matches, match_cap, counters, lane);
+                        npend = 0;
+                    }
+                    if (mm) {
+                        const int bpos = __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        rd_match e;
+                        e.stream = (int32_t)s;
+                        e.pos = (int32_t)(p0 + 32 * o + bpos);
+                        pend[npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0))] = e;
+                    }
+                    npend += nf;
+                    any = __ballot(mm != 0);
+                }
             }
         }
     }
-    // End of kernel: the four waves' leftovers leave through ONE atomic (every wave flushing
-    // its own few entries made 8192 serialized atomics = 90 us of a 110 us kernel).
-    __shared__ uint32_t left[4];
+    // End of kernel: the workgroup's leftovers leave through ONE atomic (every wave flushing
+    // its own few entries made 8192 serialized atomics = 90 us of a 110 us kernel).  What is
+    // left is issue-bound: 64 funnel shifts (v_alignbit_b32, 4-cycle class) per 128 positions.
+    __shared__ uint32_t left[RD_SEARCH_WAVES + 1];
     if (lane == 0) left[threadIdx.x >> 6] = npend;
     __syncthreads();
     if ((threadIdx.x >> 6) == 0) {
-        const uint32_t n0 = left[0], n1 = left[1], n2 = left[2], n3 = left[3];
-        const uint32_t tot = n0 + n1 + n2 + n3;
+        // exclusive prefix of the wave counts (lane v < RD_SEARCH_WAVES holds wave v's)
+        const uint32_t mine = lane < RD_SEARCH_WAVES ? left[lane] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < RD_SEARCH_WAVES; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const uint32_t tot = __shfl(incl, RD_SEARCH_WAVES - 1, 64);
         if (tot) {
             uint32_t base_slot = 0;
             if (lane == 0) base_slot = atomicAdd(&counters[RD_CNT_MATCH], tot);
             base_slot = __builtin_amdgcn_readfirstlane(base_slot);
-            for (uint32_t i = lane; i < tot; i += 64) {
-                const uint32_t wv = i < n0 ? 0 : i < n0 + n1 ? 1 : i < n0 + n1 + n2 ? 2 : 3;
-                const uint32_t off = i - (wv == 0 ? 0 : wv == 1 ? n0 : wv == 2 ? n0 + n1 : n0 + n1 + n2);
-                if (base_slot + i < match_cap) matches[base_slot + i] = pend_all[wv][off];
+#pragma unroll 1
+            for (int wv = 0; wv < RD_SEARCH_WAVES; wv++) {
+                const uint32_t n = __shfl(mine, wv, 64), off = __shfl(incl - mine, wv, 64);
+                for (uint32_t i = lane; i < n; i += 64)
+                    if (base_slot + off + i < match_cap) matches[base_slot + off + i] = pend_all[wv][i];
             }
         }
     }
@@ -462,200 +498,35 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
     const long nwords = (n_bits + 31) / 32;
     const long groups = (p_hi - base) / (32 * RD_SEARCH_OUT) + 1;
     const uint64_t total = (uint64_t)n_streams * groups;
-    uint64_t wgs = (total + 255) / 256;
+    uint64_t wgs = (total + 64 * RD_SEARCH_WAVES - 1) / (64 * RD_SEARCH_WAVES);
     static int cap = 0;
     if (!cap) {
         const char *e = getenv("RD_K2_WGS_PER_CU");  // tuning knob
-        cap = e ? atoi(e) : 8;
-        if (cap < 1 || cap > 64) cap = 8;
+        cap = e ? atoi(e) : 32 / RD_SEARCH_WAVES;  // 8 waves per SIMD
+        if (cap < 1 || cap > 64) cap = 32 / RD_SEARCH_WAVES;
     }
     if (wgs > 256ull * cap) wgs = 256ull * cap;
     // the Davis configuration (protocol.py:68-76): 14 samples/symbol, preamble 1100101110001001
     // (bit m of the mask = symbol m -> 0x91D3)
     if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
-        hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride,
+        hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
                            n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
     else
-        hipLaunchKernelGGL((k_search<0, 0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, bits, bits_stride, n_streams,
+        hipLaunchKernelGGL((k_search<0, 0, 0>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride, n_streams,
                            nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_slice: one lane per match.  Decides which call(s) report it (py:194), reserves record
-// slots (one atomic per wave) and packs packet_symbols bits at stride S (py:197-200).
-// k_rssi: one wave per record, evaluates the reference's RSSI/SNR windows (py:207-236) in
-// float64 (<= 2*preamble_length fir9 outputs per record, 64 lanes in parallel).
+// k_slice_rssi: one WAVE per match.  Decides which call(s) report it (py:194), packs
+// packet_symbols bits at stride S (py:197-200: lane k reads symbol k, a ballot packs them) and
+// evaluates the reference's RSSI/SNR windows (py:207-236) with all 64 lanes.
+// Record i belongs to match i.  A position on a block boundary is reported by two calls (q = B in
+// call b, q = 0 in call b+1): its second record is appended at recs[match_cap + k], k counted by
+// RD_CNT_REC.  A match that no call reports leaves stream = -1.  Per-call duplicates (py:203-205)
+// are dropped by the host when it puts the records in the reference's order.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rd_bit_at(const uint32_t *w, long nwords, long o) {
     return (rd_word_at(w, nwords, o >> 5) >> (o & 31)) & 1u;
-}
-
-// Writes one record (all fields except RSSI/SNR, which k_rssi fills for the survivors).
-__device__ __forceinline__ void rd_write_record(rd_packet *o, const uint32_t *w, long nwords, long pos,
-                                                const rd_devcfg &cfg, int stream, int call, long q) {
-    if (cfg.K == 80 && cfg.S == 14) {
-        // Davis packet: 80 bit reads with compile-time offsets, all issued before the first use
-        // (the generic loop below waits for every load in turn: 80 memory latencies per record)
-        uint32_t word[80];
-#pragma unroll
-        for (int i = 0; i < 80; i++) word[i] = rd_word_at(w, nwords, (pos + 14L * i) >> 5);
-        uint32_t bytes[10];
-#pragma unroll
-        for (int bi = 0; bi < 10; bi++) {
-            uint32_t byte = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = bi * 8 + k;
-                byte = (byte << 1) | ((word[i] >> ((pos + 14L * i) & 31)) & 1u);
-            }
-            bytes[bi] = byte;
-        }
-#pragma unroll
-        for (int bi = 0; bi < RD_MAX_PKT_BYTES; bi++) o->data[bi] = bi < 10 ? (uint8_t)bytes[bi] : (uint8_t)0;
-    } else
-    for (int bi = 0; bi < RD_MAX_PKT_BYTES; bi++) {
-        uint32_t byte = 0;
-        if (bi < cfg.nbytes)
-            for (int k = 0; k < 8; k++) {
-                const int i = bi * 8 + k;
-                if (i < cfg.K) byte = (byte << 1) | rd_bit_at(w, nwords, pos + (long)i * cfg.S);
-            }
-        o->data[bi] = (uint8_t)byte;
-    }
-    o->stream = stream; o->call = call; o->index = (int32_t)q; o->nbytes = cfg.nbytes;
-    o->rssi = 0.0; o->snr = 0.0;
-}
-
-__global__ __launch_bounds__(64) void k_slice(const uint32_t *bits, size_t bits_stride, long nwords, rd_devcfg cfg,
-                                              const rd_match *matches, uint32_t match_cap, int batch_mode,
-                                              int n_calls, int call, rd_packet *recs, uint32_t rec_cap,
-                                              uint32_t *counters) {
-    const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_MATCH];
-    if (count > match_cap) count = match_cap;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounds = (count + stride - 1) / stride;  // wave-uniform trip count
-    for (uint32_t rnd = 0; rnd < rounds; rnd++) {
-        const uint32_t i = rnd * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool have = i < count;
-        rd_match mt = {0, 0};
-        if (have) mt = matches[i];
-        const uint32_t *w = bits + (size_t)mt.stream * bits_stride;
-        // Which call(s) report this position (py:194, q <= B): in batch mode call b sees absolute
-        // positions w_b <= p <= w_b + B with w_b = (b+1)B - L, so p is reported by one call, or by
-        // two when it falls on a block boundary (q = B in call b, q = 0 in call b+1).
-        long b0 = call, b1 = -1, q0 = mt.pos, q1 = 0;
-        bool ok0 = have, ok1 = false;
-        if (batch_mode) {
-            const long pl = (long)mt.pos + cfg.L;  // >= B because p >= B - L
-            b0 = pl / cfg.B - 1;
-            q0 = (long)mt.pos - ((b0 + 1) * (long)cfg.B - cfg.L);
-            ok0 = have && b0 >= 0 && b0 < n_calls;
-            b1 = b0 - 1;
-            q1 = q0 + cfg.B;
-            ok1 = have && (pl % cfg.B == 0) && b1 >= 0 && b1 < n_calls;
-        }
-        // one slot reservation per wave and round for both
-        const uint64_t m0 = __ballot(ok0), m1 = __ballot(ok1);
-        if (!(m0 | m1)) continue;
-        const uint32_t n0 = (uint32_t)__popcll(m0);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[RD_CNT_REC], n0 + (uint32_t)__popcll(m1));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (ok0) {
-            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0));
-            if (slot < rec_cap) rd_write_record(&recs[slot], w, nwords, mt.pos, cfg, mt.stream, (int)b0, q0);
-        }
-        if (ok1) {
-            const uint32_t slot = base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0));
-            if (slot < rec_cap) rd_write_record(&recs[slot], w, nwords, mt.pos, cfg, mt.stream, (int)b1, q1);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Per-call dedupe on the device (py:203-205).  Among the records of one call that carry the
-// same bytes the reference keeps the first in its search order, i.e. the smallest
-// (index % S, index).  k_dedupe_insert finds/creates the table slot of (stream, call, data) and
-// atomically lowers its order key; k_dedupe_select keeps the record whose key is the slot's
-// minimum and compacts the survivors.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t rd_rec_hash(const rd_packet *r) {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (((uint64_t)(uint32_t)r->stream << 32) | (uint32_t)r->call);
-    const uint32_t *d = (const uint32_t *)r->data;
-#pragma unroll
-    for (int i = 0; i < RD_MAX_PKT_BYTES / 4; i++) {
-        h = (h ^ d[i]) * 0xFF51AFD7ED558CCDull;
-        h ^= h >> 32;
-    }
-    return h;
-}
-
-__device__ __forceinline__ bool rd_rec_same(const rd_packet *a, const rd_packet *b) {
-    if (a->stream != b->stream || a->call != b->call) return false;
-    const uint32_t *x = (const uint32_t *)a->data, *y = (const uint32_t *)b->data;
-    bool same = true;
-#pragma unroll
-    for (int i = 0; i < RD_MAX_PKT_BYTES / 4; i++) same &= x[i] == y[i];
-    return same;
-}
-
-__device__ __forceinline__ uint64_t rd_order_key(const rd_packet *r, int S) {
-    return ((uint64_t)(uint32_t)(r->index % S) << 32) | (uint32_t)r->index;
-}
-
-__global__ __launch_bounds__(256) void k_dedupe_insert(const rd_packet *recs, uint32_t rec_cap, rd_dedupe_ws ws, int S,
-                                                       const uint32_t *counters) {
-    uint32_t count = counters[RD_CNT_REC];
-    if (count > rec_cap) count = rec_cap;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const rd_packet *r = &recs[i];
-    const uint64_t key = rd_order_key(r, S);
-    unsigned long long *tab = (unsigned long long *)ws.table;
-    uint32_t slot = (uint32_t)rd_rec_hash(r) & (ws.slots - 1);
-    for (uint32_t probe = 0; probe < ws.slots; probe++) {
-        const unsigned long long owner = atomicCAS(&tab[2 * (size_t)slot], ~0ull, (unsigned long long)i);
-        if (owner == ~0ull || rd_rec_same(&recs[owner], r)) {
-            atomicMin(&tab[2 * (size_t)slot + 1], (unsigned long long)key);
-            ws.slot_of[i] = slot;
-            return;
-        }
-        slot = (slot + 1) & (ws.slots - 1);
-    }
-    ws.slot_of[i] = 0xFFFFFFFFu;  // table full: cannot happen (slots >= 2 * rec_cap); kept as survivor
-}
-
-__global__ __launch_bounds__(256) void k_dedupe_select(const rd_packet *recs, uint32_t rec_cap, rd_dedupe_ws ws, int S,
-                                                       uint32_t *counters) {
-    uint32_t count = counters[RD_CNT_REC];
-    if (count > rec_cap) count = rec_cap;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    bool keep = false;
-    if (i < count) {
-        const uint32_t slot = ws.slot_of[i];
-        keep = slot == 0xFFFFFFFFu || ws.table[2 * (size_t)slot + 1] == rd_order_key(&recs[i], S);
-    }
-    const uint64_t km = __ballot(keep);
-    if (!km) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[RD_CNT_FINAL], (uint32_t)__popcll(km));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (!keep) return;
-    const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
-    const uint4 *src = (const uint4 *)&recs[i];
-    uint4 *out = (uint4 *)&ws.final_recs[dst];
-#pragma unroll
-    for (int j = 0; j < (int)(sizeof(rd_packet) / 16); j++) out[j] = src[j];
-}
-
-static void rd_launch_dedupe(const rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, int S, uint32_t *counters,
-                             hipStream_t st) {
-    hipMemsetAsync(ws.table, 0xFF, (size_t)ws.slots * 16, st);
-    const uint32_t wgs = (rec_cap + 255) / 256;
-    hipLaunchKernelGGL(k_dedupe_insert, dim3(wgs), dim3(256), 0, st, recs, rec_cap, ws, S, counters);
-    hipLaunchKernelGGL(k_dedupe_select, dim3(wgs), dim3(256), 0, st, recs, rec_cap, ws, S, counters);
 }
 
 __device__ __forceinline__ double rd_wave_sum(double v) {
@@ -666,10 +537,10 @@ __device__ __forceinline__ double rd_wave_sum(double v) {
 
 // filtered[j] = f[origin + j - 1], j in [0, B] (py:133,161: newest block only); origin is
 // call*B in batch mode and 0 (the newest block's first sample) in streaming mode.
+// rssi / snr of the packet at window index q: valid in lane 0.
 template <class View>
-__device__ __forceinline__ void rd_rssi_record(const View &v, long origin, const rd_devcfg &cfg, rd_packet *o,
-                                               int lane) {
-    const long q = o->index;
+__device__ __forceinline__ void rd_rssi_f64(const View &v, long origin, const rd_devcfg &cfg, long q, int lane,
+                                            double &rssi, double &snr) {
     const long ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
     const long pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
     double noise = 0.0, sig = 0.0;
@@ -683,8 +554,8 @@ __device__ __forceinline__ void rd_rssi_record(const View &v, long origin, const
     if (lane == 0) {
         const double noise_power = (q > ns) ? noise / (double)(q - ns) : 1e-9;
         const double signal_power = (pe > q) ? sig / (double)(pe - q) : __builtin_nan("");
-        o->rssi = signal_power > 0 ? 10.0 * log10(signal_power) : -120.0;
-        o->snr = noise_power > 0 ? 10.0 * log10(signal_power / noise_power) : 50.0;
+        rssi = signal_power > 0 ? 10.0 * log10(signal_power) : -120.0;
+        snr = noise_power > 0 ? 10.0 * log10(signal_power / noise_power) : 50.0;
     }
 }
 
@@ -743,9 +614,8 @@ __device__ __forceinline__ float rd_wave_sum_f32(float v) {
 
 // uint8 input: the window means are evaluated in fp32 (|f|^2 to ~1e-6 relative; 10*log10 through
 // v_log_f32, ~3e-6 dB; the tolerance on RSSI/SNR is 1e-3 dB).
-__device__ __forceinline__ void rd_rssi_record_u8(const rd_stream_view &v, long origin, const rd_devcfg &cfg,
-                                                  rd_packet *o, int lane) {
-    const long q = o->index;
+__device__ __forceinline__ void rd_rssi_u8(const rd_stream_view &v, long origin, const rd_devcfg &cfg, long q,
+                                           int lane, double &rssi, double &snr) {
     const long ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
     const long pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
     constexpr int PER = 8;  // outputs per lane per pass: 64 * 8 = 512 window positions per pass
@@ -771,54 +641,132 @@ __device__ __forceinline__ void rd_rssi_record_u8(const rd_stream_view &v, long 
         const float noise_power = (q > ns) ? noise / (float)(q - ns) : 1e-9f;
         const float signal_power = (pe > q) ? sig / (float)(pe - q) : __builtin_nanf("");
         // 10*log10(x) = 3.0102999566 * log2(x)
-        o->rssi = signal_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power)) : -120.0;
-        o->snr = noise_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power / noise_power)) : 50.0;
+        rssi = signal_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power)) : -120.0;
+        snr = noise_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power / noise_power)) : 50.0;
     }
 }
 
-__global__ __launch_bounds__(256) void k_rssi(rd_layout lay, rd_devcfg cfg, int batch_mode, rd_packet *recs,
-                                              uint32_t rec_cap, const uint32_t *counters) {
-    const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_FINAL];
-    if (count > rec_cap) count = rec_cap;
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
-        rd_packet *o = &recs[i];
+#ifndef RD_SLICE_MIN_WGS
+#define RD_SLICE_MIN_WGS 1  // (8 = 64 VGPRs was tried: 14 spills, 73 us instead of 58)
+#endif
+// where the RSSI windows read their samples from: the uint8 streams or the complex128 ring
+struct rd_u8_src {
+    rd_layout lay;
+    __device__ __forceinline__ void rssi(int stream, long origin, const rd_devcfg &cfg, long q, int lane, double &r,
+                                         double &s) const {
         rd_stream_view v;
-        v.base = lay.iq + (size_t)o->stream * lay.stream_stride;
+        v.base = lay.iq + (size_t)stream * lay.stream_stride;
         v.valid_from = lay.valid_from;
         v.n = lay.n_samples;
-        rd_rssi_record_u8(v, batch_mode ? (long)o->call * cfg.B : 0, cfg, o, lane);
+        rd_rssi_u8(v, origin, cfg, q, lane, r, s);
+    }
+};
+struct rd_cplx_src {
+    rd_cplx_view v;
+    __device__ __forceinline__ void rssi(int, long origin, const rd_devcfg &cfg, long q, int lane, double &r,
+                                         double &s) const {
+        rd_rssi_f64(v, origin, cfg, q, lane, r, s);
+    }
+};
+
+// lanes 0..31 hold data[lane] in `byte`; lane 0 writes the header
+__device__ __forceinline__ void rd_store_record(rd_packet *o, int lane, int stream, long call, long q, int nbytes,
+                                                uint32_t byte, double rssi, double snr) {
+    if (lane < RD_MAX_PKT_BYTES) o->data[lane] = lane < nbytes ? (uint8_t)byte : (uint8_t)0;
+    if (lane == 0) {
+        o->stream = stream; o->call = (int32_t)call; o->index = (int32_t)q; o->nbytes = nbytes;
+        o->rssi = rssi; o->snr = snr;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cplx_rssi(rd_cplx_view v, rd_devcfg cfg, rd_packet *recs, uint32_t rec_cap,
-                                                   const uint32_t *counters) {
+template <class Src>
+__global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, const uint32_t *bits, size_t bits_stride, long nwords,
+                                                    rd_devcfg cfg, const rd_match *matches, uint32_t match_cap,
+                                                    int batch_mode, int n_calls, int call, rd_packet *recs,
+                                                    uint32_t *counters) {
     const int lane = threadIdx.x & 63;
-    uint32_t count = counters[RD_CNT_FINAL];
-    if (count > rec_cap) count = rec_cap;
+    uint32_t count = counters[RD_CNT_MATCH];
+    if (count > match_cap) count = match_cap;
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw)
-        rd_rssi_record(v, 0, cfg, &recs[i], lane);
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
+        const int stream = __builtin_amdgcn_readfirstlane(matches[i].stream);
+        const long pos = __builtin_amdgcn_readfirstlane(matches[i].pos);
+        // Which call(s) report this position (py:194, q <= B): in batch mode call b sees absolute
+        // positions w_b <= p <= w_b + B with w_b = (b+1)B - L, so p is reported by one call, or by
+        // two when it falls on a block boundary (q = B in call b, q = 0 in call b+1).
+        long b0 = call, b1 = -1, q0 = pos, q1 = 0;
+        bool ok0 = true, ok1 = false;
+        if (batch_mode) {
+            const long pl = pos + cfg.L;  // >= B because p >= B - L
+            b0 = pl / cfg.B - 1;
+            q0 = pos - ((b0 + 1) * (long)cfg.B - cfg.L);
+            ok0 = b0 >= 0 && b0 < n_calls;
+            b1 = b0 - 1;
+            q1 = q0 + cfg.B;
+            ok1 = (pl % cfg.B == 0) && b1 >= 0 && b1 < n_calls;
+        }
+        // symbols 64r + lane of the packet; byte bi = symbols 8bi .. 8bi+7, first symbol = MSB; a
+        // last partial byte is right-aligned (the bits are shifted in one by one, py:197-200).
+        // The same fetch yields the symbols of the packets one position earlier and later: when
+        // one of them carries the same bits (an oversampled burst matches at 2-4 adjacent
+        // positions) and precedes this one in the reference's order within the same call, this
+        // record is certain to be dropped by the per-call dedupe (py:203-205) and is skipped here,
+        // before its RSSI windows are read.
+        const uint32_t *w = bits + (size_t)stream * bits_stride;
+        uint32_t byte = 0;
+        bool same_prev = true, same_next = true;
+        for (int r = 0; r * 64 < cfg.K; r++) {
+            const int k = 64 * r + lane;
+            const uint32_t tri = k < cfg.K ? rd_bits32_at(w, nwords, pos - 1 + (long)k * cfg.S) : 0u;
+            const uint64_t mp = __ballot((tri & 1u) != 0), m = __ballot((tri & 2u) != 0), mn = __ballot((tri & 4u) != 0);
+            same_prev &= mp == m;
+            same_next &= mn == m;
+            const int bi = lane - 8 * r;
+            if (bi >= 0 && bi < 8) {
+                const int have = cfg.K - 8 * lane;  // symbols in this byte
+                const uint32_t rev = __builtin_bitreverse32((uint32_t)((m >> (8 * bi)) & 0xFF)) >> 24;
+                byte = have >= 8 ? rev : have > 0 ? rev >> (8 - have) : 0u;
+            }
+        }
+        // q-1 precedes q in (q % S, q) order unless q % S == 0; q+1 precedes q only when q % S == S-1
+        auto superseded = [&](long q) {
+            const long ph = q % cfg.S;
+            return (same_prev && q >= 1 && ph != 0) || (same_next && q + 1 <= cfg.B && ph == cfg.S - 1);
+        };
+        rd_packet *o = &recs[i];
+        const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);
+        if (!(use0 || use1)) {
+            rd_store_record(o, lane, -1, 0, 0, 0, 0u, 0.0, 0.0);
+            continue;
+        }
+        const long pb = use0 ? b0 : b1, pq = use0 ? q0 : q1;
+        double rssi = 0.0, snr = 0.0;
+        src.rssi(stream, batch_mode ? pb * cfg.B : 0, cfg, pq, lane, rssi, snr);
+        rd_store_record(o, lane, stream, pb, pq, cfg.nbytes, byte, rssi, snr);
+        if (use0 && use1) {
+            uint32_t slot = 0;
+            if (lane == 0) slot = atomicAdd(&counters[RD_CNT_REC], 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);  // < match_cap: at most one per match
+            src.rssi(stream, b1 * cfg.B, cfg, q1, lane, rssi, snr);
+            rd_store_record(&recs[(size_t)match_cap + slot], lane, stream, b1, q1, cfg.nbytes, byte, rssi, snr);
+        }
+    }
 }
 
-static uint32_t rd_rssi_grid(uint32_t rec_cap) {
-    uint32_t wgs = (rec_cap + 3) / 4;
+static uint32_t rd_slice_grid(uint32_t match_cap) {
+    uint32_t wgs = (match_cap + 3) / 4;
     if (wgs > 4096) wgs = 4096;
     return wgs ? wgs : 1;
 }
 
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, uint32_t rec_cap, const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st) {
-    uint32_t wgs = (match_cap + 63) / 64;  // 64-thread workgroups: one wave each, spread over the CUs
-    if (wgs > 4096) wgs = 4096;
-    if (wgs == 0) wgs = 1;
-    hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(64), 0, st, bits, bits_stride, (n_bits + 31) / 32, cfg, matches,
-                       match_cap, batch_mode, n_calls, call, recs, rec_cap, counters);
-    rd_launch_dedupe(recs, rec_cap, ws, cfg.S, counters, st);
-    hipLaunchKernelGGL(k_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, lay, cfg, batch_mode, ws.final_recs,
-                       rec_cap, counters);
+                     rd_packet *recs, uint32_t *counters, hipStream_t st) {
+    rd_u8_src src;
+    src.lay = lay;
+    hipLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
+                       bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap, batch_mode, n_calls, call, recs,
+                       counters);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -835,16 +783,20 @@ __device__ __forceinline__ uint32_t rd_swap_bits8(uint32_t b) {  // protocol.py:
     return b;
 }
 
-__global__ __launch_bounds__(256) void k_parse_select(const rd_packet *recs, uint32_t rec_cap, rd_parsed *parsed,
+__global__ __launch_bounds__(256) void k_parse_select(const rd_packet *recs, uint32_t match_cap, rd_parsed *parsed,
                                                       uint32_t *counters) {
-    uint32_t count = counters[RD_CNT_FINAL];
-    if (count > rec_cap) count = rec_cap;
+    // records: [0, matches) one per match (stream < 0: reported by no call) and
+    // [match_cap, match_cap + RD_CNT_REC) the second records of block-boundary positions
+    uint32_t nprim = counters[RD_CNT_MATCH], nextra = counters[RD_CNT_REC];
+    if (nprim > match_cap) nprim = match_cap;
+    if (nextra > match_cap) nextra = match_cap;
+    const uint32_t rec_cap = 2 * match_cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool ok = false;
     uint8_t sw[RD_MAX_PKT_BYTES];
     int nb = 0;
-    if (i < count) {
+    if ((i < nprim || (i >= match_cap && i - match_cap < nextra)) && recs[i].stream >= 0) {
         const rd_packet *r = &recs[i];
         nb = r->nbytes;
         uint32_t crc = 0;
@@ -907,9 +859,10 @@ __global__ __launch_bounds__(256) void k_freq_err(rd_layout lay, rd_devcfg cfg, 
     }
 }
 
-void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *final_recs, uint32_t rec_cap,
+void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,
                      rd_parsed *parsed, uint32_t *counters, hipStream_t st) {
-    hipLaunchKernelGGL(k_parse_select, dim3((rec_cap + 255) / 256), dim3(256), 0, st, final_recs, rec_cap, parsed,
+    const uint32_t rec_cap = 2 * match_cap;
+    hipLaunchKernelGGL(k_parse_select, dim3((rec_cap + 255) / 256), dim3(256), 0, st, recs, match_cap, parsed,
                        counters);
     uint32_t wgs = (rec_cap + 3) / 4;
     if (wgs > 2048) wgs = 2048;
@@ -1028,17 +981,12 @@ void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double 
 }
 
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
-                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t rec_cap,
-                          const rd_dedupe_ws &ws, uint32_t *counters, hipStream_t st) {
-    uint32_t wgs = (match_cap + 63) / 64;
-    if (wgs > 4096) wgs = 4096;
-    if (wgs == 0) wgs = 1;
-    rd_cplx_view v = {lay.x, lay.valid_from, lay.n};
-    hipLaunchKernelGGL(k_slice, dim3(wgs), dim3(64), 0, st, bits, (size_t)0, (n_bits + 31) / 32, cfg, matches,
-                       match_cap, 0, 0, call, recs, rec_cap, counters);
-    rd_launch_dedupe(recs, rec_cap, ws, cfg.S, counters, st);
-    hipLaunchKernelGGL(k_cplx_rssi, dim3(rd_rssi_grid(rec_cap)), dim3(256), 0, st, v, cfg, ws.final_recs, rec_cap,
-                       counters);
+                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t *counters,
+                          hipStream_t st) {
+    rd_cplx_src src;
+    src.v = rd_cplx_view{lay.x, lay.valid_from, lay.n};
+    hipLaunchKernelGGL(k_slice_rssi<rd_cplx_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
+                       (size_t)0, (n_bits + 31) / 32, cfg, matches, match_cap, 0, 0, call, recs, counters);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -39,9 +39,13 @@ def main():
             out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True, cwd=os.getcwd())
             try:
                 t = json.loads(out.stdout.strip().splitlines()[-1])
-                res[name].append(t[key])
+                res[name].append(t if key == "all" else t[key])
             except Exception:
                 print(name, "FAILED", out.stderr[-400:])
+    if key == "all":
+        for name, v in res.items():
+            print(f"{name:24s} " + "  ".join(f"{k[:-3]} {min(x[k] for x in v):.4f}" for k in v[0] if k != "runs"))
+        return
     for name, v in res.items():
         print(f"{name:24s} {key} min {min(v):.4f}  med {sorted(v)[len(v)//2]:.4f}  all {['%.4f' % x for x in v]}")
 
