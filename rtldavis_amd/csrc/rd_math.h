@@ -49,15 +49,22 @@
 #define RD_DC ((float)(127.4 * RD_CDC))
 
 // ---- rigorous fp32 error bound (units: raw byte values) -------------------------------
-// f_hat = fma chain  acc0 = -D; acc_{k+1} = fma(T_k, s_k, acc_k), k = 0..4, with
-// s_k = w_a +- w_b exact integers (|s_k| <= 510, |w_c| <= 255), T_k = fl32(c_k) * (+-1).
-//   rounding of the 5 fmas : <= 2^-24 * sum_k |partial_k|
-//                            <= 2^-24 * (5*2.44 + 255*(2c0 + (2c0+2c1) + (..+2c2) + (..+2c3) + 1))
-//                            =  2^-24 * (12.2 + 255*2.3152) = 3.60e-5
-//   tap rounding           : <= 2^-24 * sum_k c_k |s_k| <= 2^-24 * 255 = 1.52e-5
-//   rounding of D          : <= 2^-23 (ulp(2.44)/2 = 1.2e-7)
-// total < 5.15e-5; RD_E_ABS adds margin for the second-order terms of the numerator bound.
-#define RD_E_ABS 5.5e-5f
+// f_hat = fma chain  acc0 = -+D; acc_{k+1} = fma(T_k, s_k, acc_k), k = 0..4, with
+// T_k = +-fl32(c_k) and exact small integers s_k: s0 = w1+w9, s2 = w3+w7 in [0, 510] (raw bytes
+// are not negative), s1 = w2-w8, s3 = w4-w6 in [-255, 255], s4 = w5 in [0, 255].  Two samples
+// apart the Fs/4 rotation flips the sign, so T0, T2, T4 alternate (+,-,+ or -,+,-) and acc0
+// (the rotated DC term, |D| = 2.44) opposes T0; T1, T3 take either sign.  Interval bounds of the
+// partial sums for the pattern (+,.,-,.,+), the other one being its mirror image:
+//   p0 = -D + c0 s0          in [ -2.44,   6.58]          |p0| <=   6.58
+//   p1 = p0 +- c1 s1         in [-14.72,  18.86]          |p1| <=  18.86
+//   p2 = p1 - c2 s2          in [-77.16,  18.86]          |p2| <=  77.16
+//   p3 = p2 +- c3 s3         in [-127.5,  69.20]          |p3| <= 127.50
+//   p4 = p3 + c4 s4          in [-127.5, 127.50]          |p4| <= 127.50
+//   rounding of the 5 fmas : <= 2^-24 * sum |p_k| = 2^-24 * 357.6            = 2.13e-5
+//   tap rounding           : <= 2^-24 * sum_k c_k max|s_k| = 2^-24 * 192.3   = 1.15e-5
+//   rounding of D          : <= 2^-23 (ulp(2.44)/2)                          = 1.2e-7
+// total < 3.30e-5; RD_E_ABS adds margin for the second-order terms of the numerator bound.
+#define RD_E_ABS 3.5e-5f
 // With a,b,c,d the true components (|.| <= F + E, F = max |component of f_hat| over the run):
 // |num_hat - num| <= E(|a|+|b|+|c|+|d|) + 2E^2 + 3*2^-24 F^2 <= F*(4E + 2^-22 F) + 6E^2.
 // 6E^2 < 2e-8; the additive 1e-7 and the factor (1 + 2^-20) cover it and the fp32
