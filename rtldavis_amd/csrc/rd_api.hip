@@ -362,7 +362,7 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
                      b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
     if (b->timing && b->timing_detail) hipEventRecord(b->ev[3], st);
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
-                    b->d_recs, batch_cnt(b), st);
+                    b->d_recs, nullptr, batch_cnt(b), st);
     if (b->parse) {
         if (!b->d_parsed) hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed));
         if (b->d_parsed) rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
@@ -630,12 +630,12 @@ struct rd_demod {
     uint32_t *d_blockbits = nullptr, *d_win[2] = {nullptr, nullptr}, *d_fix = nullptr, *d_cnt = nullptr;
     int cur_win = 0;
     rd_match *d_matches = nullptr;
-    rd_packet *d_recs = nullptr;
     double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
     double *h_tmp = nullptr;        // pinned mirror of d_tmp (state accessors)
     uint8_t *h_in = nullptr;        // pinned staging of one input block
     uint32_t *h_cnt = nullptr;      // pinned
-    rd_packet *h_recs = nullptr;    // pinned, rec_cap entries
+    rd_packet *h_recs = nullptr;    // pinned + mapped, rec_cap entries: written by the slice kernel
+    rd_packet *d_recs_map = nullptr; // device address of h_recs
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     bool fast_ok = false;
 };
@@ -681,12 +681,12 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_fix, (size_t)h->fix_cap * 4));
     HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
     HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
-    HIPCHK(hipMalloc(&h->d_recs, (size_t)h->rec_cap * sizeof(rd_packet)));
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&h->h_in, std::max(16 * B, NS * 2 * B), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_tmp, 2 * (2 * B + 2) * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&h->d_recs_map, h->h_recs, 0));
     h->dev_ready = true;
     return RD_OK;
 }
@@ -696,7 +696,7 @@ extern "C" void rd_destroy(rd_demod *h) {
     if (h->dev_ready && g_hip_pid == getpid()) {
         hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_stage); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
-        hipFree(h->d_matches); hipFree(h->d_recs); hipFree(h->d_tmp);
+        hipFree(h->d_matches); hipFree(h->d_tmp);
         hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs); hipHostFree(h->h_tmp);
     }
     delete h;
@@ -806,23 +806,19 @@ static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_pac
     rd_launch_search(h->d_win[nw], lw, h->NS, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
     if (!h->cplx_mode)
         rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], lw, (long)L, h->dc, h->d_matches, h->match_cap, 0,
-                        0, (int)seen_before, h->d_recs, h->d_cnt, st);
+                        0, (int)seen_before, nullptr, h->d_recs_map, h->d_cnt, st);
     else
         rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
-                             (int)seen_before, h->d_recs, h->d_cnt, st);
+                             (int)seen_before, nullptr, h->d_recs_map, h->d_cnt, st);
     HIPCHK(hipGetLastError());
-    // counters and the first records come back with the block; polling wait (see wait_stream)
-    const uint32_t spec = std::min<uint32_t>(h->rec_cap, 32 * (uint32_t)NS);
+    // The counters come back with the block; the few records of a block are written by the slice
+    // kernel straight into pinned host memory (no copy to wait for; for the thousands of records of
+    // a batch run the same was measured slower than a device buffer + one copy).  Polling wait.
     HIPCHK(hipMemcpyAsync(h->h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost, st));
     rc = wait_stream(st);
     if (rc) return rc;
     h->seen = seen_before + 1;
     const uint32_t nrec = std::min(h->h_cnt[RD_CNT_MATCH], h->match_cap);  // one record per match (no call overlap here)
-    if (nrec > spec) {
-        rc = copy_d2h(h->h_recs + spec, h->d_recs + spec, (size_t)(nrec - spec) * sizeof(rd_packet), st);
-        if (rc) return rc;
-    }
     std::vector<rd_packet> recs;
     order_and_dedupe(h->h_recs, nrec, h->dc.S, recs);
     *n = (int)recs.size();

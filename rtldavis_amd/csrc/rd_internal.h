@@ -56,10 +56,12 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 // recs holds 2 * match_cap entries: recs[i] is match i's record (stream = -1 when no call reports
 // it); the second record of a position on a block boundary (q = B in call b and q = 0 in call
 // b+1, py:194) goes to recs[match_cap + k], k < RD_CNT_REC.  Per-call duplicates (py:203-205) are
-// left to the host, which orders the records anyway.
+// left to the host, which orders the records anyway.  recs (device memory) and recs_host (the
+// device address of pinned, mapped host memory) are both optional: the kernel stores to each that
+// is given; with recs_host the records need no device-to-host copy.
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, uint32_t *counters, hipStream_t st);
+                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st);
 // Parser.parse front half (protocol.py:290-311) over the records of a batch run (layout as
 // above): CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
 void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,
@@ -83,8 +85,8 @@ void rd_launch_cplx_bits(const rd_cplx_layout &lay, uint32_t *bits, hipStream_t 
 void rd_launch_cplx_disc(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
 void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double *out, hipStream_t st);
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
-                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t *counters,
-                          hipStream_t st);
+                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, rd_packet *recs_host,
+                          uint32_t *counters, hipStream_t st);
 void rd_launch_lut(const uint8_t *in, double *out, size_t n_cplx, hipStream_t st);
 
 // stage kernels on device arrays (float64)

@@ -669,13 +669,40 @@ struct rd_cplx_src {
     }
 };
 
-// lanes 0..31 hold data[lane] in `byte`; lane 0 writes the header
-__device__ __forceinline__ void rd_store_record(rd_packet *o, int lane, int stream, long call, long q, int nbytes,
-                                                uint32_t byte, double rssi, double snr) {
-    if (lane < RD_MAX_PKT_BYTES) o->data[lane] = lane < nbytes ? (uint8_t)byte : (uint8_t)0;
+// Lanes 0..31 hold data[lane] in `byte`, lane 0 holds rssi / snr.  The 64-byte record is put
+// together across lanes 0..15 (one dword each) and leaves as ONE coalesced store per destination:
+// `dev` (device memory, read by the parse kernels) and/or `host` (pinned host memory mapped into
+// the device: the record crosses the bus as a single 64-byte write and needs no copy afterwards).
+__device__ __forceinline__ void rd_store_record(rd_packet *dev, rd_packet *host, int lane, int stream, long call, long q,
+                                                int nbytes, uint32_t byte, double rssi, double snr) {
+    const uint32_t b = (lane < RD_MAX_PKT_BYTES && lane < nbytes) ? (byte & 0xFFu) : 0u;
+    const int d = (lane - 4) & 7;  // data dword of lanes 4..11
+    const uint32_t dw = __shfl(b, 4 * d, 64) | (__shfl(b, 4 * d + 1, 64) << 8) | (__shfl(b, 4 * d + 2, 64) << 16) |
+                        (__shfl(b, 4 * d + 3, 64) << 24);
+    const uint64_t rb = __builtin_bit_cast(uint64_t, rssi), sb = __builtin_bit_cast(uint64_t, snr);
+    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((uint32_t)rb), r_hi = __builtin_amdgcn_readfirstlane((uint32_t)(rb >> 32));
+    const uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+    static_assert(sizeof(rd_packet) == 64, "record layout");
+    uint32_t v = dw;
+    if (lane == 0) v = (uint32_t)stream;
+    if (lane == 1) v = (uint32_t)(int32_t)call;
+    if (lane == 2) v = (uint32_t)(int32_t)q;
+    if (lane == 3) v = (uint32_t)nbytes;
+    if (lane == 12) v = r_lo;
+    if (lane == 13) v = r_hi;
+    if (lane == 14) v = s_lo;
+    if (lane == 15) v = s_hi;
+    if (lane < 16) {
+        if (dev) ((uint32_t *)dev)[lane] = v;
+        if (host) ((uint32_t *)host)[lane] = v;
+    }
+}
+
+// a match that no call reports, or that the per-call dedupe is certain to drop: stream = -1
+__device__ __forceinline__ void rd_store_void(rd_packet *dev, rd_packet *host, int lane) {
     if (lane == 0) {
-        o->stream = stream; o->call = (int32_t)call; o->index = (int32_t)q; o->nbytes = nbytes;
-        o->rssi = rssi; o->snr = snr;
+        if (dev) dev->stream = -1;
+        if (host) host->stream = -1;
     }
 }
 
@@ -683,7 +710,7 @@ template <class Src>
 __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, const uint32_t *bits, size_t bits_stride, long nwords,
                                                     rd_devcfg cfg, const rd_match *matches, uint32_t match_cap,
                                                     int batch_mode, int n_calls, int call, rd_packet *recs,
-                                                    uint32_t *counters) {
+                                                    rd_packet *recs_host, uint32_t *counters) {
     const int lane = threadIdx.x & 63;
     uint32_t count = counters[RD_CNT_MATCH];
     if (count > match_cap) count = match_cap;
@@ -733,22 +760,24 @@ __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, c
             const long ph = q % cfg.S;
             return (same_prev && q >= 1 && ph != 0) || (same_next && q + 1 <= cfg.B && ph == cfg.S - 1);
         };
-        rd_packet *o = &recs[i];
+        rd_packet *o = recs ? &recs[i] : nullptr, *oh = recs_host ? &recs_host[i] : nullptr;
         const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);
         if (!(use0 || use1)) {
-            rd_store_record(o, lane, -1, 0, 0, 0, 0u, 0.0, 0.0);
+            rd_store_void(o, oh, lane);
             continue;
         }
         const long pb = use0 ? b0 : b1, pq = use0 ? q0 : q1;
         double rssi = 0.0, snr = 0.0;
         src.rssi(stream, batch_mode ? pb * cfg.B : 0, cfg, pq, lane, rssi, snr);
-        rd_store_record(o, lane, stream, pb, pq, cfg.nbytes, byte, rssi, snr);
+        rd_store_record(o, oh, lane, stream, pb, pq, cfg.nbytes, byte, rssi, snr);
         if (use0 && use1) {
             uint32_t slot = 0;
             if (lane == 0) slot = atomicAdd(&counters[RD_CNT_REC], 1u);
             slot = __builtin_amdgcn_readfirstlane(slot);  // < match_cap: at most one per match
             src.rssi(stream, b1 * cfg.B, cfg, q1, lane, rssi, snr);
-            rd_store_record(&recs[(size_t)match_cap + slot], lane, stream, b1, q1, cfg.nbytes, byte, rssi, snr);
+            const size_t xi = (size_t)match_cap + slot;
+            rd_store_record(recs ? &recs[xi] : nullptr, recs_host ? &recs_host[xi] : nullptr, lane, stream, b1, q1,
+                            cfg.nbytes, byte, rssi, snr);
         }
     }
 }
@@ -761,12 +790,12 @@ static uint32_t rd_slice_grid(uint32_t match_cap) {
 
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, uint32_t *counters, hipStream_t st) {
+                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st) {
     rd_u8_src src;
     src.lay = lay;
     hipLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
                        bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap, batch_mode, n_calls, call, recs,
-                       counters);
+                       recs_host, counters);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -981,12 +1010,12 @@ void rd_launch_cplx_filtered(const rd_cplx_layout &lay, long t0, long n, double 
 }
 
 void rd_launch_cplx_slice(const rd_cplx_layout &lay, const uint32_t *bits, long n_bits, const rd_devcfg &cfg,
-                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, uint32_t *counters,
-                          hipStream_t st) {
+                          const rd_match *matches, uint32_t match_cap, int call, rd_packet *recs, rd_packet *recs_host,
+                          uint32_t *counters, hipStream_t st) {
     rd_cplx_src src;
     src.v = rd_cplx_view{lay.x, lay.valid_from, lay.n};
     hipLaunchKernelGGL(k_slice_rssi<rd_cplx_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
-                       (size_t)0, (n_bits + 31) / 32, cfg, matches, match_cap, 0, 0, call, recs, counters);
+                       (size_t)0, (n_bits + 31) / 32, cfg, matches, match_cap, 0, 0, call, recs, recs_host, counters);
 }
 
 // ------------------------------------------------------------------------------------------
