@@ -39,8 +39,8 @@ UNIQUE = 64            # unique synthetic streams, tiled to fill the batch (SURV
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=33, help="8192-sample blocks per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
