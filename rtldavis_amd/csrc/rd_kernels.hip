@@ -755,10 +755,13 @@ __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, c
                 byte = have >= 8 ? rev : have > 0 ? rev >> (8 - have) : 0u;
             }
         }
-        // q-1 precedes q in (q % S, q) order unless q % S == 0; q+1 precedes q only when q % S == S-1
+        // the reference's order inside a call: by (q % S, q) (py:171-188, phase-major search)
+        auto precedes = [&](long qa, long qb) {
+            const long pa = qa % cfg.S, pb = qb % cfg.S;
+            return pa < pb || (pa == pb && qa < qb);
+        };
         auto superseded = [&](long q) {
-            const long ph = q % cfg.S;
-            return (same_prev && q >= 1 && ph != 0) || (same_next && q + 1 <= cfg.B && ph == cfg.S - 1);
+            return (same_prev && q >= 1 && precedes(q - 1, q)) || (same_next && q + 1 <= cfg.B && precedes(q + 1, q));
         };
         rd_packet *o = recs ? &recs[i] : nullptr, *oh = recs_host ? &recs_host[i] : nullptr;
         const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);

@@ -1,6 +1,7 @@
 """GPU parity tests (MI355X): the HIP path, called through the C ABI, against the golden
 fixtures generated from the real reference and against the C oracle on the same inputs."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -187,6 +188,19 @@ def test_random_configs_against_c_oracle(dsp, batchmod, S, P, K, B, nb, ns):
         return  # more than 64 packets in one call: the streaming wrapper's documented limit
     got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(calls) for p in ps]
     assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[0]]
+
+
+def test_soak_small_configs_dense_duplicates(dsp, batchmod):
+    """Randomised small PacketConfigs (symbol length 1.., preambles of 1-6 symbols, 32-256-sample
+    blocks) on repetitive inputs: dense matches, long runs of identical packets at adjacent
+    positions (the slice kernel voids those it can prove the per-call dedupe drops), many
+    positions on block boundaries.  Everything against the C oracle, batch and streaming."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rd_soak", os.path.join(root, "tools", "soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.soak(150, 5, verbose=False) > 1000
 
 
 def test_batch_degenerate_inputs_take_the_exact_path(dsp, batchmod):
