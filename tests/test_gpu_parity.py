@@ -201,6 +201,9 @@ def test_soak_small_configs_dense_duplicates(dsp, batchmod):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.soak(150, 5, verbose=False) > 1000
+    # production config, bursts placed on and around block boundaries (q = B / q = 0 twins)
+    n, at_edge = mod.soak_bursts(768, 3, verbose=False)
+    assert n >= 768 and at_edge >= 5
 
 
 def test_batch_degenerate_inputs_take_the_exact_path(dsp, batchmod):

@@ -77,5 +77,47 @@ def soak(n_cases, seed, verbose=True):
     return nrec
 
 
+def soak_bursts(n_streams, seed, verbose=True):
+    """Production config: one burst per stream with its preamble placed on and around the block
+    boundaries (q = B in one call and q = 0 in the next, py:194), several amplitudes and noise
+    levels, 4-block streams; batch path and (for a few streams) the streaming handle."""
+    from rtldavis_amd import synth
+    rng = np.random.default_rng(seed)
+    B, nb = 8192, 4
+    cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", B)
+    ocfg = CO.make_cfg()
+    raws = []
+    for i in range(n_streams):
+        # the packet's preamble starts 32 symbols after the burst start
+        edge = int(rng.integers(1, nb)) * B
+        start = edge - 32 * 14 + int(rng.integers(-20, 21)) - int(rng.integers(0, 2)) * B // 2
+        raws.append(synth.synth_stream(int(rng.integers(0, 1 << 30)), n_samples=B * nb, amplitude=float(rng.choice([0.1, 0.3, 0.5, 0.9])),
+                                       noise=float(rng.choice([0.01, 0.05, 0.1])), start=max(64, start), margin=64))
+    raw = np.stack(raws)
+    want, wbits = CO.demod_batch(raw, ocfg, threads=8, want_bits=True)
+    bd = batch.BatchDemodulator(cfg, n_streams, nb)
+    res = bd.demodulate(raw)
+    n = 0
+    twice = 0
+    for i in range(n_streams):
+        assert np.array_equal(bd.bits(i), wbits[i]), (i, "bits")
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+        exp = [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
+        assert got == exp, (i, got, exp)
+        twice += sum(1 for g in got if g[1] == B)
+        n += len(got)
+    for i in range(min(n_streams, 24)):
+        dem = dsp.Demodulator(cfg)
+        calls = [dem.demodulate(raw[i][2 * B * b: 2 * B * (b + 1)]) for b in range(nb)]
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(calls) for p in ps]
+        assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]], (i, "streaming")
+    if verbose:
+        print(f"burst soak ok: {n_streams} streams, {n} packets, {twice} reported at q = B")
+    return n, twice
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bursts":
+        soak_bursts(int(sys.argv[2]) if len(sys.argv) > 2 else 512, int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+        sys.exit(0)
     soak(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
