@@ -6,7 +6,9 @@
 //                    a rigorous guard band (rd_math.h) feeding
 //   k_fixup        : exact integer re-evaluation of guard-band runs
 //   k_search       : Demodulator._search py:171-188 (go:115-131) on packed bits, bit-parallel
-//   k_slice        : Demodulator._slice py:190-246 (packing, RSSI/SNR windows)
+//   k_slice_rssi   : Demodulator._slice py:190-246 (call assignment, packing, the certain cases of
+//                    the per-call dedupe, RSSI/SNR windows), one wave per match
+//   k_parse_select / k_freq_err : Parser.parse front half, protocol.py:290-311 (opt-in)
 //   k_disc/k_filt  : float64 discriminate / fir9 values for the state mirrors py:133-134
 //   k_cplx_*       : the complex-input branch py:144-150 in float64
 //   stage kernels  : one float64 kernel per reference stage function

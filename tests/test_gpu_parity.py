@@ -352,8 +352,9 @@ def test_batch_edge_q_equals_block_size(dsp, batchmod):
 
 
 def test_two_bursts_in_one_window_dedupe_order(dsp, batchmod):
-    """Several matches with different and with identical bytes inside one call: the on-device
-    dedupe must keep exactly what dsp.py:203-205 keeps, in the reference's order."""
+    """Several matches with different and with identical bytes inside one call: the dedupe (certain
+    cases on the device, the rest on the host) must keep exactly what dsp.py:203-205 keeps, in the
+    reference's order."""
     g = load_json("two_bursts.json")
     seeds = sorted(g, key=int)
     raws = np.stack([synth.synth_two_bursts(int(s), g[s]["gap"]) for s in seeds])
@@ -368,8 +369,8 @@ def test_two_bursts_in_one_window_dedupe_order(dsp, batchmod):
 
 
 def test_dedupe_many_identical_records_one_call(dsp, batchmod):
-    """One stream repeated: every stream must produce the same packets (hash-table collisions
-    between streams must not merge records of different streams)."""
+    """One stream repeated: every stream must produce the same packets (records of different
+    streams with equal bytes must never be merged by the dedupe)."""
     g = load_json("two_bursts.json")
     raw = synth.synth_two_bursts(300, g["300"]["gap"])
     n = 700
