@@ -227,6 +227,7 @@ struct rd_batch {
     long n_samples;      // per stream
     size_t bits_stride;  // words per stream
     bool dev_ready = false, fast_ok = false, ran = false, timing = false, timing_detail = false;
+    bool fetched = false;  // batch_finish has seen the last run complete
     uint8_t *d_iq = nullptr;
     size_t iq_bytes = 0;
     uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
@@ -367,13 +368,14 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
         if (!b->d_parsed) hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed));
         if (b->d_parsed) rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
     }
-    if (b->timing) hipEventRecord(b->ev[4], st);
     // results come back with the run: counters plus as many records as the last run produced
     // (+25 %); rd_batch_results fetches the remainder if this run produced more.
     // The copies run on their own stream so that another batch's kernels queued on `st` need
-    // not wait for them.
-    hipEventRecord(b->kdone, st);
-    hipStreamWaitEvent(b->copy_stream, b->kdone, 0);
+    // not wait for them.  Every event recorded between two kernels idles the GPU for a few
+    // microseconds, so a timed run's end-of-run event doubles as the copy stream's trigger.
+    hipEvent_t last = b->timing ? b->ev[4] : b->kdone;
+    hipEventRecord(last, st);
+    hipStreamWaitEvent(b->copy_stream, last, 0);
     hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
     const uint32_t spec = std::min(b->match_cap, b->spec_recs);
     if (spec)
@@ -389,7 +391,10 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     b->stream = st;
     const rd_layout lay = batch_layout(b);
-    if (b->ran) HIPCHK(hipStreamWaitEvent(st, b->done, 0));  // the previous run's readback of d_recs
+    // the previous run's readback of d_cnt / d_recs must be over before they are rewritten: the host
+    // has already waited for it if the results were fetched (the normal order), else the stream waits
+    if (b->ran && !b->fetched) HIPCHK(hipStreamWaitEvent(st, b->done, 0));
+    b->fetched = false;
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;
     uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * RD_CNT_SLOTS;
@@ -448,6 +453,7 @@ static int batch_finish(rd_batch *b) {
         }
         if (!redo_search) {
             b->last_match = b->h_cnt[RD_CNT_MATCH];
+            b->fetched = true;
             return RD_OK;
         }
         const uint32_t zero[4] = {0, 0, 0, 0};  // matches, boundary records, (unused), parsed

@@ -671,32 +671,22 @@ struct rd_cplx_src {
     }
 };
 
-// Lanes 0..31 hold data[lane] in `byte`, lane 0 holds rssi / snr.  The 64-byte record is put
-// together across lanes 0..15 (one dword each) and leaves as ONE coalesced store per destination:
-// `dev` (device memory, read by the parse kernels) and/or `host` (pinned host memory mapped into
-// the device: the record crosses the bus as a single 64-byte write and needs no copy afterwards).
+// Lanes 0..31 hold data[lane] in `byte`, lane 0 holds rssi / snr.  Destinations: `dev` (device
+// memory) and/or `host` (pinned host memory mapped into the device, used by the streaming handle:
+// a block's few records need no copy afterwards).  Plain byte + header stores: assembling the 64
+// bytes across 16 lanes for one coalesced store (four ds_bpermute + readfirstlanes) was measured
+// 7 us slower per launch.
 __device__ __forceinline__ void rd_store_record(rd_packet *dev, rd_packet *host, int lane, int stream, long call, long q,
                                                 int nbytes, uint32_t byte, double rssi, double snr) {
-    const uint32_t b = (lane < RD_MAX_PKT_BYTES && lane < nbytes) ? (byte & 0xFFu) : 0u;
-    const int d = (lane - 4) & 7;  // data dword of lanes 4..11
-    const uint32_t dw = __shfl(b, 4 * d, 64) | (__shfl(b, 4 * d + 1, 64) << 8) | (__shfl(b, 4 * d + 2, 64) << 16) |
-                        (__shfl(b, 4 * d + 3, 64) << 24);
-    const uint64_t rb = __builtin_bit_cast(uint64_t, rssi), sb = __builtin_bit_cast(uint64_t, snr);
-    const uint32_t r_lo = __builtin_amdgcn_readfirstlane((uint32_t)rb), r_hi = __builtin_amdgcn_readfirstlane((uint32_t)(rb >> 32));
-    const uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
-    static_assert(sizeof(rd_packet) == 64, "record layout");
-    uint32_t v = dw;
-    if (lane == 0) v = (uint32_t)stream;
-    if (lane == 1) v = (uint32_t)(int32_t)call;
-    if (lane == 2) v = (uint32_t)(int32_t)q;
-    if (lane == 3) v = (uint32_t)nbytes;
-    if (lane == 12) v = r_lo;
-    if (lane == 13) v = r_hi;
-    if (lane == 14) v = s_lo;
-    if (lane == 15) v = s_hi;
-    if (lane < 16) {
-        if (dev) ((uint32_t *)dev)[lane] = v;
-        if (host) ((uint32_t *)host)[lane] = v;
+#pragma unroll
+    for (int dst = 0; dst < 2; dst++) {
+        rd_packet *o = dst ? host : dev;
+        if (!o) continue;
+        if (lane < RD_MAX_PKT_BYTES) o->data[lane] = lane < nbytes ? (uint8_t)byte : (uint8_t)0;
+        if (lane == 0) {
+            o->stream = stream; o->call = (int32_t)call; o->index = (int32_t)q; o->nbytes = nbytes;
+            o->rssi = rssi; o->snr = snr;
+        }
     }
 }
 
@@ -757,13 +747,14 @@ __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, c
                 byte = have >= 8 ? rev : have > 0 ? rev >> (8 - have) : 0u;
             }
         }
-        // the reference's order inside a call: by (q % S, q) (py:171-188, phase-major search)
-        auto precedes = [&](long qa, long qb) {
-            const long pa = qa % cfg.S, pb = qb % cfg.S;
-            return pa < pb || (pa == pb && qa < qb);
-        };
+        // The reference's order inside a call is by (q % S, q) (py:171-188, phase-major search):
+        // q-1 precedes q unless its phase is larger (it wraps to S-1 when q % S == 0, S > 1);
+        // q+1 precedes q only when its phase is smaller (it wraps to 0 when q % S == S-1, S > 1).
         auto superseded = [&](long q) {
-            return (same_prev && q >= 1 && precedes(q - 1, q)) || (same_next && q + 1 <= cfg.B && precedes(q + 1, q));
+            const uint32_t S = (uint32_t)cfg.S, ph = (uint32_t)q % S;
+            const bool prev_first = S == 1 || ph != 0;
+            const bool next_first = S > 1 && ph == S - 1;
+            return (same_prev && q >= 1 && prev_first) || (same_next && q + 1 <= cfg.B && next_first);
         };
         rd_packet *o = recs ? &recs[i] : nullptr, *oh = recs_host ? &recs_host[i] : nullptr;
         const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);
