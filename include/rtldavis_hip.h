@@ -186,6 +186,42 @@ int rd_quantize(const double *in, uint8_t *out, size_t n);
  * indices in the reference's order; *n = count (RD_ERR_CAPACITY if > cap). */
 int rd_search(const rd_config *cfg, const uint8_t *quantized, size_t n, int32_t *indices, int cap, int *count);
 
+/* ---------------------------------------------------------------------------------------------
+ * Wideband front end: one uint8 IQ capture at decim * out_rate samples/s ->
+ * one out_rate uint8 IQ stream per channel, e.g. the 51 US hop channels (protocol.py:119-171) out
+ * of one 26.88 MS/s capture, written straight into a batch demodulator's input buffer.
+ * The reference has no channelizer (it retunes one dongle per hop, runners/rtlsdr.py:51,72):
+ * parity is unpinned; the definition is in rtldavis_amd/csrc/rd_channelizer.hip and restated in
+ * float64 by oracle/channelizer_oracle.py.  Output bytes may differ from the float64 model by one
+ * LSB where the fp32 sum lands on a rounding boundary.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rd_chan_config {
+    int32_t out_rate;   /* Hz per channel (19200 * symbol_length = 268800, protocol.py:309) */
+    int32_t decim;      /* wideband rate = decim * out_rate */
+    int32_t n_taps;     /* length of the real low-pass prototype */
+    int32_t n_channels;
+    double gain;        /* applied before the 8-bit quantiser clip(rint(z * 127.6 + 127.4), 0, 255) */
+} rd_chan_config;
+typedef struct rd_chan rd_chan;
+
+/* taps: n_taps doubles; shift_hz[c]: the wideband frequency (Hz, relative to the capture's centre)
+ * that channel c moves to 0 Hz of its output - for rtldavis the channel centre plus out_rate / 4,
+ * because the demodulator's Fs/4 rotation (dsp.py:42-49) expects the carrier at -Fs/4.  No device
+ * work (safe before fork). */
+int rd_chan_create(const rd_chan_config *cfg, const double *taps, const int64_t *shift_hz, rd_chan **out);
+void rd_chan_destroy(rd_chan *h);
+/* Host -> device copy of a capture (uint8 I,Q interleaved), or the device address of the resident
+ * capture buffer (at least n_wide_samples) for a producer on the GPU. */
+int rd_chan_upload(rd_chan *h, const uint8_t *wide_iq, size_t nbytes);
+int rd_chan_input_ptr(rd_chan *h, size_t n_wide_samples, void **dev_ptr);
+/* Channelize output samples 0 .. n_out-1 (n_out <= capture length / decim; zero history before
+ * the capture) of every channel into device memory: channel c at dst_dev + c * dst_stream_stride,
+ * 2 bytes per sample - rd_batch_input_ptr's layout with stride 2 * n_blocks * block_size.
+ * Asynchronous on hip_stream (NULL = default stream). */
+int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_stream_stride, void *hip_stream);
+/* Same, into a host array uint8 [n_channels][n_out][2] (synchronous). */
+int rd_chan_run_host(rd_chan *h, size_t n_out, uint8_t *out_host, size_t nbytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,11 @@ class RdTiming(C.Structure):
                 ("slice_ms", C.c_float), ("total_ms", C.c_float), ("runs", C.c_int32)]
 
 
+class RdChanConfig(C.Structure):
+    _fields_ = [("out_rate", C.c_int32), ("decim", C.c_int32), ("n_taps", C.c_int32), ("n_channels", C.c_int32),
+                ("gain", C.c_double)]
+
+
 # name -> (restype, argtypes); exactly the functions include/rtldavis_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -77,6 +82,12 @@ SIGNATURES = {
     "rd_discriminate": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
     "rd_quantize": (C.c_int, [_P, _P, C.c_size_t]),
     "rd_search": (C.c_int, [C.POINTER(RdConfig), _P, C.c_size_t, _P, C.c_int, C.POINTER(C.c_int)]),
+    "rd_chan_create": (C.c_int, [C.POINTER(RdChanConfig), _P, _P, C.POINTER(_P)]),
+    "rd_chan_destroy": (None, [_P]),
+    "rd_chan_upload": (C.c_int, [_P, _P, C.c_size_t]),
+    "rd_chan_input_ptr": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "rd_chan_run": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, _P]),
+    "rd_chan_run_host": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
 }
 
 _lib = None

@@ -56,6 +56,19 @@ static pid_t g_hip_pid = 0;  // pid that first touched the device through this l
 
 // HIP state does not survive fork(): a child of a process that already used the device
 // must not reuse it.  Handles created before fork hold no device state (lazy init).
+// for rd_channelizer.hip (same error slot, same fork rule)
+int rd_fail_msg(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+static int ensure_device();
+int rd_ensure_device_public(void) { return ensure_device(); }
+
 static int ensure_device() {
     const pid_t me = getpid();
     if (g_hip_pid != 0 && g_hip_pid != me)

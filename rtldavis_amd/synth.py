@@ -104,6 +104,37 @@ def synth_streams(seeds, n_samples: int = STREAM_SAMPLES) -> np.ndarray:
     return out
 
 
+def synth_wideband(seeds, shifts_hz, n_out: int, decim: int = 100, out_rate: int = SYMBOL_LENGTH * 19200,
+                   amplitude: float = 0.12, noise: float = 0.02, noise_seed: int = 1234):
+    """One wideband capture (uint8 I,Q interleaved, decim*out_rate samples/s, n_out*decim samples)
+    holding one burst per entry: burst i is the packet synth_stream(seeds[i]) carries, at
+    shifts_hz[i] Hz from the capture's centre (+ a random cfo of +-2 kHz), starting somewhere
+    between the first and the last 8192 output samples.  Returns (raw, [(payload_hex, start_out)])."""
+    fw = decim * out_rate
+    n = n_out * decim
+    rng = np.random.default_rng(noise_seed)
+    x = noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    info = []
+    for seed, shift in zip(seeds, shifts_hz):
+        r = np.random.default_rng(seed)
+        payload = OTA_PACKETS[int(r.integers(0, len(OTA_PACKETS)))]
+        sym = np.concatenate([np.tile(np.array([1, 0], dtype=np.uint8), 16), packet_bits(payload),
+                              np.zeros(8, dtype=np.uint8)])
+        chips = np.repeat(sym, SYMBOL_LENGTH * decim)
+        start_out = int(r.integers(BLOCK_SIZE, n_out - chips.size // decim - BLOCK_SIZE))
+        cfo = float(r.uniform(-2000.0, 2000.0))
+        lo, hi = start_out * decim, start_out * decim + chips.size
+        freq = float(shift) + cfo + np.where(chips == 1, 4800.0, -4800.0)
+        # phase of the tone from sample 0 (continuous through the burst)
+        phase = (float(shift) + cfo) * lo * (2.0 * np.pi / fw) + np.cumsum(freq) * (2.0 * np.pi / fw)
+        x[lo:hi] += amplitude * np.exp(1j * phase)
+        info.append((payload, start_out))
+    out = np.empty(2 * n, dtype=np.uint8)
+    out[0::2] = np.clip(np.rint(x.real * 127.6 + 127.4), 0, 255).astype(np.uint8)
+    out[1::2] = np.clip(np.rint(x.imag * 127.6 + 127.4), 0, 255).astype(np.uint8)
+    return out, info
+
+
 def payload_of(seed: int) -> str:
     """The on-air packet hex synth_stream(seed) carries."""
     rng = np.random.default_rng(seed)
