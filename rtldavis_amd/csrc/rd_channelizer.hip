@@ -15,14 +15,18 @@
 // output phasor's phase is an exact integer remainder.
 //
 // Kernel: VALU fp32 (8 T flops per output: 113 GFLOP for one second of 51 channels - compute-
-// bound, the 81 MB of HBM traffic would take 10 us).  A workgroup stages the (TT-1) D + T input
-// samples of TT = 64 output times in LDS as float2, with one pad slot per D samples so that the
-// lanes' stride is 2(D+1) dwords (D = 100: 202 = 10 mod 32, a 64-bit read per lane spreads over all
-// banks).  Each wave takes RD_CHAN_CPW = 4 channels with lane = output time: per tap one
-// ds_read_b64 feeds 16 fmas, the four complex taps arrive through scalar loads (wave-uniform),
-// the tap loop unrolled by 8 so that those loads are in flight together.  Measured: 1.9 ms for
-// one second of capture (27 M samples -> 51 x 270 k), 30 TFLOP/s; a bf16-MFMA formulation (inputs
-// are 8-bit integers, taps split into two bf16 terms) is the way to the next 10x and is not built.
+// bound, the 81 MB of HBM traffic would take 10 us).  A workgroup of up to 16 waves stages the
+// 63 D + T input samples of 64 output times in LDS as float2, with one pad slot per D samples so
+// that the lanes' stride is 2(D+1) dwords (D = 100: 202 = 10 mod 32, a 64-bit read per lane
+// spreads over all banks).  Each wave takes RD_CHAN_CPW = 4 channels with lane = output time; its
+// taps come through a wave-private LDS buffer (16 taps x 4 channels per chunk, fetched one chunk
+// ahead with one coalesced 16-byte load per lane) and are read back as broadcasts, so per tap one
+// ds_read_b64 (samples) + two ds_read_b128 (taps) feed 16 fmas: 53 TFLOP/s, limited by the CU's
+// one LDS pipe.  Measured and not kept: taps through scalar loads (the compiler keeps two loads
+// in flight per wave: 46 TFLOP/s); samples as half2 of the exact integers 10 k - 1274 with 1-4
+// output times per lane (fewer LDS bytes per fma, but the conversions are 4-cycle-class
+// instructions and the bigger tiles cost occupancy: 30-42 TFLOP/s).  A bf16-MFMA formulation
+// (inputs are 8-bit integers, taps split into bf16 terms) is the way to the next factor; not built.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,14 +40,16 @@
 extern int rd_fail_msg(int code, const char *fmt, ...);  // rd_api.hip: sets rd_last_error
 extern int rd_ensure_device_public(void);
 
-#define RD_CHAN_TT 64   // output times per workgroup (one per lane)
-#define RD_CHAN_CPW 4   // channels per wave and pass
-#define RD_CHAN_WAVES 4
+#define RD_CHAN_TT 64      // output times per workgroup (one per lane)
+#define RD_CHAN_CPW 4      // channels per wave (register tile)
+#define RD_CHAN_KC 16      // taps per staged chunk: KC * CPW float2 = 512 B = one 16-byte load per lane 0..31
+#define RD_CHAN_MAX_WAVES 16
 
 struct rd_chan {
     rd_chan_config cfg;
     int n_ch_pad = 0;              // channels rounded up to RD_CHAN_CPW
-    std::vector<float> h_taps;     // [n_ch_pad][T][2]  g_c[k] (re, im)
+    int t_pad = 0;                 // taps rounded up to RD_CHAN_KC (zero taps appended)
+    std::vector<float> h_taps;     // [n_ch_pad / CPW][t_pad][CPW][2]  g_c[k] (re, im), c = group * CPW + q
     std::vector<int64_t> shifts;   // Hz
     float *d_taps = nullptr;
     int64_t *d_shifts = nullptr;
@@ -54,21 +60,26 @@ struct rd_chan {
 
 __device__ __forceinline__ int rd_chan_lds_index(int n_rel, int D) { return n_rel + n_rel / D; }
 
-__global__ __launch_bounds__(64 * RD_CHAN_WAVES) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
-                                                                  const float2 *__restrict__ taps, const int64_t *shifts,
-                                                                  int T, int D, int n_ch, int n_ch_pad, long out_rate,
-                                                                  float gain, long n_out, uint8_t *out,
-                                                                  size_t out_stride) {
-    extern __shared__ float2 xs[];
+// T is the padded tap count (multiple of RD_CHAN_KC, zero taps at the end); taps layout
+// [group][k][q] float2 with group = channel / CPW, q = channel % CPW.
+__global__ __launch_bounds__(64 * RD_CHAN_MAX_WAVES) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
+                                                                      const float2 *__restrict__ taps,
+                                                                      const int64_t *shifts, int T, int D, int n_ch,
+                                                                      int n_groups, long out_rate, float gain,
+                                                                      long n_out, uint8_t *out, size_t out_stride,
+                                                                      int xs_slots) {
+    extern __shared__ float2 lds[];
+    float2 *xs = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *tbuf = lds + xs_slots + wave * (2 * RD_CHAN_KC * RD_CHAN_CPW);  // wave-private, double-buffered
     const long t0 = (long)blockIdx.x * RD_CHAN_TT;
     // stage samples n_base .. n_base + span - 1, n_base = D t0 - (T - 1)
     const long n_base = (long)D * t0 - (T - 1);
     const int span = (RD_CHAN_TT - 1) * D + T;
     for (int i = threadIdx.x; i < span; i += blockDim.x) {
         const long n = n_base + i;
-        float2 v = {0.0f, 0.0f};
+        float2 v = {0.0f, 0.0f};  // zero history before the capture (and zero padding after it)
         if (n >= 0 && n < n_wide) {
             const uint16_t iq = *(const uint16_t *)(wide + 2 * n);
             v.x = ((float)(iq & 0xFF) - 127.4f) * (1.0f / 127.6f);
@@ -78,49 +89,56 @@ __global__ __launch_bounds__(64 * RD_CHAN_WAVES) void k_channelize(const uint8_t
     }
     __syncthreads();
     const long t = t0 + lane;
-    // lane's newest sample (k = 0) sits at relative index D lane + T - 1
-    for (int c0 = (blockIdx.y * RD_CHAN_WAVES + wave) * RD_CHAN_CPW; c0 < n_ch_pad;
-         c0 += gridDim.y * RD_CHAN_WAVES * RD_CHAN_CPW) {
+    const int nwaves = blockDim.x >> 6;
+    for (int grp = blockIdx.y * nwaves + wave; grp < n_groups; grp += gridDim.y * nwaves) {  // wave-uniform
         float ar[RD_CHAN_CPW], ai[RD_CHAN_CPW];
 #pragma unroll
-        for (int j = 0; j < RD_CHAN_CPW; j++) { ar[j] = 0.0f; ai[j] = 0.0f; }
-        const float2 *g = taps + (size_t)c0 * T;
-        // tap k reads relative sample j = T-1-k of lane 0, D lane + j of this lane: padded index
-        // (D+1) lane + j + j / D.  Walk j downwards in segments of constant j / D (no division in
-        // the loop).
+        for (int q = 0; q < RD_CHAN_CPW; q++) { ar[q] = 0.0f; ai[q] = 0.0f; }
+        // chunk c = taps k in [c KC, (c+1) KC) of this group's 4 channels: 64 float2 = 32 float4
+        const float4 *gsrc = (const float4 *)(taps + (size_t)grp * T * RD_CHAN_CPW);
+        const int n_chunks = T / RD_CHAN_KC;
+        float4 pre = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (lane < 32) pre = gsrc[lane];
+        // tap k reads relative sample j = T-1-k of time 0, D n + j of time n: padded index
+        // (D+1) n + j + j / D; j walks down, its quotient and remainder by D are kept in scalars
         const float2 *xl = xs + (D + 1) * lane;
-        for (int jq = (T - 1) / D; jq >= 0; jq--) {
-            const int j_hi = min(T - 1, jq * D + D - 1), j_lo = jq * D;
-#pragma unroll 8
-            for (int j = j_hi; j >= j_lo; j--) {
-                const int k = T - 1 - j;
+        int j = T - 1, jq = (T - 1) / D, jr = (T - 1) % D;
+        for (int c = 0; c < n_chunks; c++) {
+            float2 *tb = tbuf + (c & 1) * (RD_CHAN_KC * RD_CHAN_CPW);
+            if (lane < 32) ((float4 *)tb)[lane] = pre;
+            if (c + 1 < n_chunks && lane < 32) pre = gsrc[(size_t)(c + 1) * 32 + lane];
+#pragma unroll
+            for (int kk = 0; kk < RD_CHAN_KC; kk++) {
                 const float2 x = xl[j + jq];
+                const float4 g01 = ((const float4 *)tb)[kk * 2], g23 = ((const float4 *)tb)[kk * 2 + 1];  // broadcasts
+                const float gr[4] = {g01.x, g01.z, g23.x, g23.z}, gi[4] = {g01.y, g01.w, g23.y, g23.w};
 #pragma unroll
                 for (int q = 0; q < RD_CHAN_CPW; q++) {
-                    const float2 gk = g[(size_t)q * T + k];  // wave-uniform: scalar load
-                    ar[q] = __builtin_fmaf(gk.x, x.x, ar[q]);
-                    ar[q] = __builtin_fmaf(-gk.y, x.y, ar[q]);
-                    ai[q] = __builtin_fmaf(gk.x, x.y, ai[q]);
-                    ai[q] = __builtin_fmaf(gk.y, x.x, ai[q]);
+                    ar[q] = __builtin_fmaf(gr[q], x.x, ar[q]);
+                    ar[q] = __builtin_fmaf(-gi[q], x.y, ar[q]);
+                    ai[q] = __builtin_fmaf(gr[q], x.y, ai[q]);
+                    ai[q] = __builtin_fmaf(gi[q], x.x, ai[q]);
                 }
+                j--;
+                if (jr == 0) { jr = D - 1; jq--; } else jr--;
             }
         }
         if (t < n_out) {
 #pragma unroll
-            for (int j = 0; j < RD_CHAN_CPW; j++) {
-                const int c = c0 + j;
-                if (c >= n_ch) break;
+            for (int q = 0; q < RD_CHAN_CPW; q++) {
+                const int ch = grp * RD_CHAN_CPW + q;
+                if (ch >= n_ch) break;
                 // phase = -2 pi frac(shift t / Fo), exact integer remainder
-                const long sh = shifts[c];
+                const long sh = shifts[ch];
                 long r = (long)(((__int128)sh * t) % out_rate);
                 if (r < 0) r += out_rate;
                 float sn, cs;
                 sincosf(-6.283185307179586f * ((float)r / (float)out_rate), &sn, &cs);
-                const float zr = (ar[j] * cs - ai[j] * sn) * gain, zi = (ar[j] * sn + ai[j] * cs) * gain;
+                const float zr = (ar[q] * cs - ai[q] * sn) * gain, zi = (ar[q] * sn + ai[q] * cs) * gain;
                 const float qr = fminf(fmaxf(rintf(zr * 127.6f + 127.4f), 0.0f), 255.0f);
                 const float qi = fminf(fmaxf(rintf(zi * 127.6f + 127.4f), 0.0f), 255.0f);
                 const uint16_t o = (uint16_t)((uint32_t)qr | ((uint32_t)qi << 8));
-                *(uint16_t *)(out + (size_t)c * out_stride + 2 * t) = o;
+                *(uint16_t *)(out + (size_t)ch * out_stride + 2 * t) = o;
             }
         }
     }
@@ -140,14 +158,16 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
     if (cfg->decim < 1 || cfg->decim > 4096 || cfg->n_taps < 1 || cfg->n_taps > 8192 || cfg->n_channels < 1 ||
         cfg->n_channels > 4096 || cfg->out_rate < 1 || !(cfg->gain > 0.0))
         return rd_fail_msg(RD_ERR_ARG, "channelizer config out of range");
-    const size_t lds = ((size_t)(RD_CHAN_TT - 1) * cfg->decim + cfg->n_taps);
-    if ((lds + lds / cfg->decim + 1) * sizeof(float2) > 160 * 1024)
+    const int t_pad = (cfg->n_taps + RD_CHAN_KC - 1) / RD_CHAN_KC * RD_CHAN_KC;
+    const size_t lds = ((size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad);
+    if ((lds + lds / cfg->decim + 2 + RD_CHAN_MAX_WAVES * 2 * RD_CHAN_KC * RD_CHAN_CPW) * sizeof(float2) > 160 * 1024)
         return rd_fail_msg(RD_ERR_ARG, "decim x 63 + n_taps samples do not fit the 160 KiB LDS");
     rd_chan *h = new rd_chan();
     h->cfg = *cfg;
     const int T = cfg->n_taps;
+    h->t_pad = t_pad;
     h->n_ch_pad = (cfg->n_channels + RD_CHAN_CPW - 1) / RD_CHAN_CPW * RD_CHAN_CPW;
-    h->h_taps.assign((size_t)h->n_ch_pad * T * 2, 0.0f);
+    h->h_taps.assign((size_t)h->n_ch_pad * t_pad * 2, 0.0f);
     h->shifts.assign(shift_hz, shift_hz + cfg->n_channels);
     const double wide_rate = (double)cfg->out_rate * cfg->decim;
     for (int c = 0; c < cfg->n_channels; c++)
@@ -158,8 +178,9 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
             long r = (long)(prod % fw);
             if (r < 0) r += fw;
             const double ph = 2.0 * M_PI * ((double)r / wide_rate);
-            h->h_taps[((size_t)c * T + k) * 2] = (float)(taps[k] * cos(ph));
-            h->h_taps[((size_t)c * T + k) * 2 + 1] = (float)(taps[k] * sin(ph));
+            const size_t at = ((((size_t)(c / RD_CHAN_CPW) * t_pad + k) * RD_CHAN_CPW) + c % RD_CHAN_CPW) * 2;
+            h->h_taps[at] = (float)(taps[k] * cos(ph));
+            h->h_taps[at + 1] = (float)(taps[k] * sin(ph));
         }
     *out = h;
     return RD_OK;
@@ -217,20 +238,23 @@ extern "C" int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_s
         return rd_fail_msg(RD_ERR_ARG, "n_out exceeds capture length / decim");
     if (dst_stream_stride < 2 * n_out || (dst_stream_stride & 1))
         return rd_fail_msg(RD_ERR_ARG, "destination stride too small for n_out samples");
-    const int T = h->cfg.n_taps, D = h->cfg.decim;
+    const int T = h->t_pad, D = h->cfg.decim;
     const size_t span = (size_t)(RD_CHAN_TT - 1) * D + T;
-    const size_t lds = (span + span / D + 1) * sizeof(float2);
+    const int groups = h->n_ch_pad / RD_CHAN_CPW;
+    const int waves = groups < RD_CHAN_MAX_WAVES ? groups : RD_CHAN_MAX_WAVES;
+    const size_t xs_slots = (span + span / D + 2) & ~(size_t)1;  // float2 slots, 16-byte aligned end
+    const size_t lds = (xs_slots + (size_t)waves * 2 * RD_CHAN_KC * RD_CHAN_CPW) * sizeof(float2);
     static bool attr_set = false;
     if (!attr_set) {
         CHK(hipFuncSetAttribute((const void *)k_channelize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const unsigned gx = (unsigned)((n_out + RD_CHAN_TT - 1) / RD_CHAN_TT);
-    const int groups = h->n_ch_pad / RD_CHAN_CPW;
-    const unsigned gy = (unsigned)((groups + RD_CHAN_WAVES - 1) / RD_CHAN_WAVES);
-    hipLaunchKernelGGL(k_channelize, dim3(gx, gy), dim3(64 * RD_CHAN_WAVES), lds, (hipStream_t)hip_stream, h->d_wide,
-                       (long)h->wide_n, (const float2 *)h->d_taps, h->d_shifts, T, D, h->cfg.n_channels, h->n_ch_pad,
-                       (long)h->cfg.out_rate, (float)h->cfg.gain, (long)n_out, (uint8_t *)dst_dev, dst_stream_stride);
+    const unsigned gy = (unsigned)((groups + waves - 1) / waves);
+    hipLaunchKernelGGL(k_channelize, dim3(gx, gy), dim3(64 * waves), lds, (hipStream_t)hip_stream, h->d_wide,
+                       (long)h->wide_n, (const float2 *)h->d_taps, h->d_shifts, T, D, h->cfg.n_channels, groups,
+                       (long)h->cfg.out_rate, (float)h->cfg.gain, (long)n_out, (uint8_t *)dst_dev, dst_stream_stride,
+                       (int)xs_slots);
     CHK(hipGetLastError());
     return RD_OK;
 }
