@@ -25,8 +25,13 @@
 // one LDS pipe.  Measured and not kept: taps through scalar loads (the compiler keeps two loads
 // in flight per wave: 46 TFLOP/s); samples as half2 of the exact integers 10 k - 1274 with 1-4
 // output times per lane (fewer LDS bytes per fma, but the conversions are 4-cycle-class
-// instructions and the bigger tiles cost occupancy: 30-42 TFLOP/s).  A bf16-MFMA formulation
-// (inputs are 8-bit integers, taps split into bf16 terms) is the way to the next factor; not built.
+// instructions and the bigger tiles cost occupancy: 30-42 TFLOP/s); a first version of the same
+// contraction on v_mfma_f32_32x32x2_f32 (real 128 x 1024 x N GEMM, A streamed through LDS, bytes
+// converted on fetch; bit-identical results): 52 TFLOP/s, no better than this kernel although the
+// pipe itself sustains 155 TFLOP/s (profiles/r01_ubench_mfma_f32_rate.txt) - its overheads were
+// not tracked down in this round.  MFMA is the right unit for this contraction (fp32 for 2-3x,
+// bf16 with the taps split into three bf16 terms - the inputs are 8-bit integers, exact in
+// bf16 - for the factor beyond); that kernel is the next step for this row.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
