@@ -21,15 +21,16 @@
 // spreads over all banks).  Each wave takes RD_CHAN_CPW = 4 channels with lane = output time; its
 // taps come through a wave-private LDS buffer (16 taps x 4 channels per chunk, fetched one chunk
 // ahead with one coalesced 16-byte load per lane) and are read back as broadcasts, so per tap one
-// ds_read_b64 (samples) + two ds_read_b128 (taps) feed 16 fmas: 53 TFLOP/s, limited by the CU's
-// one LDS pipe.  Measured and not kept: taps through scalar loads (the compiler keeps two loads
+// ds_read_b64 (samples) + two ds_read_b128 (taps) feed 16 fmas: 64 TFLOP/s for one second of
+// capture (0.88 ms), limited by the CU's one LDS pipe.  Measured and not kept: taps through scalar loads (the compiler keeps two loads
 // in flight per wave: 46 TFLOP/s); samples as half2 of the exact integers 10 k - 1274 with 1-4
 // output times per lane (fewer LDS bytes per fma, but the conversions are 4-cycle-class
 // instructions and the bigger tiles cost occupancy: 30-42 TFLOP/s); a first version of the same
 // contraction on v_mfma_f32_32x32x2_f32 (real 128 x 1024 x N GEMM, A streamed through LDS, bytes
-// converted on fetch; bit-identical results): 52 TFLOP/s, no better than this kernel although the
-// pipe itself sustains 155 TFLOP/s (profiles/r01_ubench_mfma_f32_rate.txt) - its overheads were
-// not tracked down in this round.  MFMA is the right unit for this contraction (fp32 for 2-3x,
+// converted on fetch; bit-identical results): 67 TFLOP/s (0.84 ms), 4 % better than this kernel
+// although the pipe itself sustains 155 TFLOP/s (profiles/r01_ubench_mfma_f32_rate.txt) - half of
+// its time is outside the MFMA loop (a fifth round of workgroups for 2112 tiles on 512 slots,
+// staging, the epilogue's phasors) and was not reworked in this round.  MFMA is the right unit for this contraction (fp32 for 2-3x,
 // bf16 with the taps split into three bf16 terms - the inputs are 8-bit integers, exact in
 // bf16 - for the factor beyond); that kernel is the next step for this row.
 #include <cmath>
@@ -55,7 +56,7 @@ struct rd_chan {
     int n_ch_pad = 0;              // channels rounded up to RD_CHAN_CPW
     int t_pad = 0;                 // taps rounded up to RD_CHAN_KC (zero taps appended)
     std::vector<float> h_taps;     // [n_ch_pad / CPW][t_pad][CPW][2]  g_c[k] (re, im), c = group * CPW + q
-    std::vector<int64_t> shifts;   // Hz
+    std::vector<int64_t> shifts;   // Hz, reduced mod out_rate
     float *d_taps = nullptr;
     int64_t *d_shifts = nullptr;
     uint8_t *d_wide = nullptr;     // resident capture, 2 bytes per sample
@@ -64,6 +65,14 @@ struct rd_chan {
 };
 
 __device__ __forceinline__ int rd_chan_lds_index(int n_rel, int D) { return n_rel + n_rel / D; }
+
+// x mod m for integer-valued 0 <= x < 2^53, 1 <= m < 2^26 (exact: one fma, one correction step)
+__device__ __forceinline__ double rd_chan_mod(double x, double m) {
+    double r = fma(-floor(x / m), m, x);
+    if (r < 0.0) r += m;
+    if (r >= m) r -= m;
+    return r;
+}
 
 // T is the padded tap count (multiple of RD_CHAN_KC, zero taps at the end); taps layout
 // [group][k][q] float2 with group = channel / CPW, q = channel % CPW.
@@ -133,12 +142,13 @@ __global__ __launch_bounds__(64 * RD_CHAN_MAX_WAVES) void k_channelize(const uin
             for (int q = 0; q < RD_CHAN_CPW; q++) {
                 const int ch = grp * RD_CHAN_CPW + q;
                 if (ch >= n_ch) break;
-                // phase = -2 pi frac(shift t / Fo), exact integer remainder
-                const long sh = shifts[ch];
-                long r = (long)(((__int128)sh * t) % out_rate);
-                if (r < 0) r += out_rate;
+                // phase = -2 pi frac(shift t / Fo), the remainders exact in float64: shifts[] holds
+                // shift mod Fo in [0, Fo), Fo < 2^26, so (shift mod Fo)(t mod Fo) < 2^52
+                const double fo = (double)out_rate;
+                const double tm = rd_chan_mod((double)t, fo);
+                const double rm = rd_chan_mod((double)shifts[ch] * tm, fo);
                 float sn, cs;
-                sincosf(-6.283185307179586f * ((float)r / (float)out_rate), &sn, &cs);
+                sincospif(-2.0f * (float)(rm / fo), &sn, &cs);
                 const float zr = (ar[q] * cs - ai[q] * sn) * gain, zi = (ar[q] * sn + ai[q] * cs) * gain;
                 const float qr = fminf(fmaxf(rintf(zr * 127.6f + 127.4f), 0.0f), 255.0f);
                 const float qi = fminf(fmaxf(rintf(zi * 127.6f + 127.4f), 0.0f), 255.0f);
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(64 * RD_CHAN_MAX_WAVES) void k_channelize(const uin
 extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, const int64_t *shift_hz, rd_chan **out) {
     if (!cfg || !taps || !shift_hz || !out) return rd_fail_msg(RD_ERR_ARG, "null argument");
     if (cfg->decim < 1 || cfg->decim > 4096 || cfg->n_taps < 1 || cfg->n_taps > 8192 || cfg->n_channels < 1 ||
-        cfg->n_channels > 4096 || cfg->out_rate < 1 || !(cfg->gain > 0.0))
+        cfg->n_channels > 4096 || cfg->out_rate < 1 || cfg->out_rate >= (1 << 26) || !(cfg->gain > 0.0))
         return rd_fail_msg(RD_ERR_ARG, "channelizer config out of range");
     const int t_pad = (cfg->n_taps + RD_CHAN_KC - 1) / RD_CHAN_KC * RD_CHAN_KC;
     const size_t lds = ((size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad);
@@ -173,7 +183,8 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
     h->t_pad = t_pad;
     h->n_ch_pad = (cfg->n_channels + RD_CHAN_CPW - 1) / RD_CHAN_CPW * RD_CHAN_CPW;
     h->h_taps.assign((size_t)h->n_ch_pad * t_pad * 2, 0.0f);
-    h->shifts.assign(shift_hz, shift_hz + cfg->n_channels);
+    h->shifts.resize(cfg->n_channels);  // shift mod Fo in [0, Fo): all the output phasor needs
+    for (int c = 0; c < cfg->n_channels; c++) h->shifts[c] = ((shift_hz[c] % cfg->out_rate) + cfg->out_rate) % cfg->out_rate;
     const double wide_rate = (double)cfg->out_rate * cfg->decim;
     for (int c = 0; c < cfg->n_channels; c++)
         for (int k = 0; k < T; k++) {
