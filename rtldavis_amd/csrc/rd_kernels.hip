@@ -716,13 +716,14 @@ __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, c
         long b0 = call, b1 = -1, q0 = pos, q1 = 0;
         bool ok0 = true, ok1 = false;
         if (batch_mode) {
-            const long pl = pos + cfg.L;  // >= B because p >= B - L
-            b0 = pl / cfg.B - 1;
+            // p + L >= B because p >= B - L, and < 2^32 (n_samples < 2^31): 32-bit division
+            const uint32_t pl = (uint32_t)(pos + cfg.L), bq = pl / (uint32_t)cfg.B, br = pl - bq * (uint32_t)cfg.B;
+            b0 = (long)bq - 1;
             q0 = pos - ((b0 + 1) * (long)cfg.B - cfg.L);
             ok0 = b0 >= 0 && b0 < n_calls;
             b1 = b0 - 1;
             q1 = q0 + cfg.B;
-            ok1 = (pl % cfg.B == 0) && b1 >= 0 && b1 < n_calls;
+            ok1 = br == 0 && b1 >= 0 && b1 < n_calls;
         }
         // symbols 64r + lane of the packet; byte bi = symbols 8bi .. 8bi+7, first symbol = MSB; a
         // last partial byte is right-aligned (the bits are shifted in one by one, py:197-200).
