@@ -33,6 +33,7 @@ def test_struct_layouts_match_header():
     assert _lib.RdPacket.data.offset == 16 and _lib.RdPacket.rssi.offset == 48
     assert C.sizeof(_lib.RdTiming) == 24
     assert C.sizeof(_lib.RdParsed) == 6 * 4 + 32 + 2 * 8
+    assert C.sizeof(_lib.RdChanConfig) == 4 * 4 + 8 and _lib.RdChanConfig.gain.offset == 16
 
 
 def test_packet_config_mirrors_reference():
@@ -93,6 +94,25 @@ def test_no_silent_cpu_fallback():
         batch.BatchDemodulator(cfg, 2, 2).demodulate(np.zeros((2, 32768), dtype=np.uint8))
     with pytest.raises(_lib.HipError):
         dsp.quantize(np.zeros(4), np.zeros(4, np.uint8))
+
+
+def test_channelizer_argument_checks_and_no_fallback():
+    """rd_chan_create validates without touching the device; without a GPU the compute calls raise."""
+    from rtldavis_amd import _lib, channelizer
+    with pytest.raises(ValueError):
+        channelizer.Channelizer([914963100], centre_hz=914963100, decim=0)          # no decimation factor
+    with pytest.raises(ValueError):
+        channelizer.Channelizer([902419338], centre_hz=990000000)                   # outside the captured band
+    with pytest.raises(ValueError):
+        channelizer.Channelizer([914963100], gain=0.0)
+    with pytest.raises(ValueError):
+        channelizer.Channelizer([914963100], taps=np.ones(9000))                    # more taps than the kernel stages
+    cz = channelizer.Channelizer()                                                  # host state only
+    assert cz.n_channels == 51 and cz.shift_hz[25] == 67200 and cz.taps.size == 512
+    if _lib.lib().rd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.HipError):
+        cz.upload(np.zeros(2 * 100 * 64, np.uint8))
 
 
 def test_product_never_imports_the_oracle():
