@@ -48,6 +48,8 @@ class Channelizer:
                  out_rate: int = OUT_RATE, if_hz: Optional[int] = None) -> None:
         self.out_rate = int(out_rate)
         self.decim = int(decim)
+        if self.decim < 1 or self.out_rate < 1:
+            raise ValueError("decim and out_rate must be positive")
         self.wide_rate = self.out_rate * self.decim
         self.if_hz = -self.out_rate // 4 if if_hz is None else int(if_hz)
         self.taps = np.ascontiguousarray(design_taps(wide_rate=self.wide_rate) if taps is None else taps, np.float64)
