@@ -14,25 +14,31 @@
 // with Fw the wideband rate, D the decimation, Fo = Fw / D; shift_c an integer number of Hz, so the
 // output phasor's phase is an exact integer remainder.
 //
-// Kernel: VALU fp32 (8 T flops per output: 113 GFLOP for one second of 51 channels - compute-
-// bound, the 81 MB of HBM traffic would take 10 us).  A workgroup of up to 16 waves stages the
-// 63 D + T input samples of 64 output times in LDS as float2, with one pad slot per D samples so
-// that the lanes' stride is 2(D+1) dwords (D = 100: 202 = 10 mod 32, a 64-bit read per lane
-// spreads over all banks).  Each wave takes RD_CHAN_CPW = 4 channels with lane = output time; its
-// taps come through a wave-private LDS buffer (16 taps x 4 channels per chunk, fetched one chunk
-// ahead with one coalesced 16-byte load per lane) and are read back as broadcasts, so per tap one
-// ds_read_b64 (samples) + two ds_read_b128 (taps) feed 16 fmas: 64 TFLOP/s for one second of
-// capture (0.88 ms), limited by the CU's one LDS pipe.  Measured and not kept: taps through scalar loads (the compiler keeps two loads
-// in flight per wave: 46 TFLOP/s); samples as half2 of the exact integers 10 k - 1274 with 1-4
-// output times per lane (fewer LDS bytes per fma, but the conversions are 4-cycle-class
-// instructions and the bigger tiles cost occupancy: 30-42 TFLOP/s); a first version of the same
-// contraction on v_mfma_f32_32x32x2_f32 (real 128 x 1024 x N GEMM, A streamed through LDS, bytes
-// converted on fetch; bit-identical results): 67 TFLOP/s (0.84 ms), 4 % better than this kernel
-// although the pipe itself sustains 155 TFLOP/s (profiles/r01_ubench_mfma_f32_rate.txt) - half of
-// its time is outside the MFMA loop (a fifth round of workgroups for 2112 tiles on 512 slots,
-// staging, the epilogue's phasors) and was not reworked in this round.  MFMA is the right unit for this contraction (fp32 for 2-3x,
-// bf16 with the taps split into three bf16 terms - the inputs are 8-bit integers, exact in
-// bf16 - for the factor beyond); that kernel is the next step for this row.
+// Kernel: bf16 MFMA (v_mfma_f32_32x32x16_bf16) - the one dense contraction in this repo.  As a real
+// GEMM, C[m][n] = sum_kappa A[m][kappa] B[kappa][n] with
+//   m     = 2 c + part  (part 0 = re, 1 = im of channel c; rows 2c, 2c+1 land in one lane's registers)
+//   kappa = 2 i + comp  (comp 0 = I, 1 = Q of window sample i = T-1-k, i.e. ascending in memory)
+//   A[2c][2i] = g_r, A[2c][2i+1] = -g_i, A[2c+1][2i] = g_i, A[2c+1][2i+1] = g_r    (g = g_c[T-1-i])
+//   B[2i + comp][n] = b_comp[D (t0 + n) - (T-1) + i] - 128
+// The samples are 8-bit integers: b - 128 is EXACT in bf16, and lut(b) = (b - 128 + 0.6) / 127.6, so
+// z = (sum + 0.6 (1 + j) sum_k g_c[k]) / 127.6 with the second term a per-channel constant (a short
+// table for the first outputs of a capture, whose history is zero).  The fp32 taps are split into
+// three bf16 terms (hi + mid + lo reproduces 24 bits), i.e. three MFMAs per tile and K step into the
+// same fp32 accumulator: products are exact, sums are fp32 - the same error class as an fp32 chain.
+// 8 T flops per output: 113 GFLOP for one second of 51 channels; HBM traffic is 81 MB.
+// A workgroup = 4 waves = 256 output times x a group of 4 row blocks (64 channels); wave w owns row
+// block w and all eight 32-time blocks (8 accumulator tiles = 128 registers).  The 255 D + T input
+// samples are staged once in LDS as bf16 pairs (I - 128, Q - 128) - 104 KiB - so a B fragment is one
+// aligned ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free); the A operand streams from
+// L2 through a double-buffered 12-KiB LDS chunk per K step, fetched two steps ahead in registers.
+// Per K step a wave issues 11 LDS reads and 24 MFMAs.
+// Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.36 ms = 2780x real time; the
+// fp32 VALU kernel this replaced took 0.88 ms (64 TFLOP/s, bound by the CU's LDS pipe: every fma
+// needed 2.5 bytes from LDS), an fp32-MFMA version 0.84 ms.  Steps on the way: converting the B
+// bytes per fragment in each wave 0.55 ms (one wave per SIMD cannot hide ~25 VALU instructions per
+// three MFMAs), A chunks one step ahead only 0.55 -> 0.46 with two.  Left on the table: the MFMA
+// pipe is busy a quarter of the time (64 barriers per workgroup, a fifth round for 1056 tiles on
+// 256 CUs at one workgroup per CU).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,25 +52,34 @@
 extern int rd_fail_msg(int code, const char *fmt, ...);  // rd_api.hip: sets rd_last_error
 extern int rd_ensure_device_public(void);
 
-#define RD_CHAN_TT 64      // output times per workgroup (one per lane)
-#define RD_CHAN_CPW 4      // channels per wave (register tile)
-#define RD_CHAN_KC 16      // taps per staged chunk: KC * CPW float2 = 512 B = one 16-byte load per lane 0..31
-#define RD_CHAN_MAX_WAVES 16
+#define RD_CHAN_TB 8                        // 32-time blocks per wave
+#define RD_CHAN_TT (32 * RD_CHAN_TB)        // output times per workgroup
+#define RD_CHAN_RBG 4                       // row blocks (32 rows = 16 channels) per workgroup: one per wave
+#define RD_CHAN_KC 8                        // window samples per staged A chunk (one K step)
+#define RD_CHAN_Q_BYTES (3 * RD_CHAN_RBG * 64 * 16)  // A bytes per K step: 3 terms x 4 row blocks x 64 lanes x 16 B
+#ifndef RD_CHAN_NPF
+#define RD_CHAN_NPF 2                       // A chunks in flight in registers
+#endif
+#define RD_CHAN_EARLY 64                    // outputs per channel with a partial-history DC term kept in a table
+
+typedef float rd_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
 
 struct rd_chan {
     rd_chan_config cfg;
-    int n_ch_pad = 0;              // channels rounded up to RD_CHAN_CPW
+    int n_groups = 0;              // groups of 64 channels
     int t_pad = 0;                 // taps rounded up to RD_CHAN_KC (zero taps appended)
-    std::vector<float> h_taps;     // [n_ch_pad / CPW][t_pad][CPW][2]  g_c[k] (re, im), c = group * CPW + q
+    int n_early = 0;               // outputs whose window reaches before the capture: ceil((t_pad - 1) / D)
+    std::vector<uint16_t> h_amat;  // bf16 A operand in fragment order [group][K step][term][row block][lane][8]
+    std::vector<float> h_dc;       // [channel][RD_CHAN_EARLY + 1][2]: 0.6 (1+j) sum of the taps a given output sees
     std::vector<int64_t> shifts;   // Hz, reduced mod out_rate
-    float *d_taps = nullptr;
+    uint16_t *d_amat = nullptr;
+    float *d_dc = nullptr;
     int64_t *d_shifts = nullptr;
     uint8_t *d_wide = nullptr;     // resident capture, 2 bytes per sample
     size_t wide_cap = 0, wide_n = 0;
     bool dev_ready = false;
 };
-
-__device__ __forceinline__ int rd_chan_lds_index(int n_rel, int D) { return n_rel + n_rel / D; }
 
 // x mod m for integer-valued 0 <= x < 2^53, 1 <= m < 2^26 (exact: one fma, one correction step)
 __device__ __forceinline__ double rd_chan_mod(double x, double m) {
@@ -74,87 +89,146 @@ __device__ __forceinline__ double rd_chan_mod(double x, double m) {
     return r;
 }
 
-// T is the padded tap count (multiple of RD_CHAN_KC, zero taps at the end); taps layout
-// [group][k][q] float2 with group = channel / CPW, q = channel % CPW.
-__global__ __launch_bounds__(64 * RD_CHAN_MAX_WAVES) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
-                                                                      const float2 *__restrict__ taps,
-                                                                      const int64_t *shifts, int T, int D, int n_ch,
-                                                                      int n_groups, long out_rate, float gain,
-                                                                      long n_out, uint8_t *out, size_t out_stride,
-                                                                      int xs_slots) {
-    extern __shared__ float2 lds[];
-    float2 *xs = lds;
+// T is the padded tap count (multiple of RD_CHAN_KC, zero taps appended), D a multiple of 4.
+__global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
+                                                    const uint4 *__restrict__ amat, const float2 *__restrict__ dc,
+                                                    const int64_t *shifts, int T, int D, int n_ch, int n_early,
+                                                    long out_rate, float gain, long n_out, uint8_t *out,
+                                                    size_t out_stride, int xs_bytes) {
+    extern __shared__ uint8_t lds[];
+    uint8_t *xs = lds;                            // window samples 0 .. span-1 as bf16 pairs (I - 128, Q - 128)
+    uint4 *abuf = (uint4 *)(lds + xs_bytes);      // 2 chunks x 2 K steps x RD_CHAN_Q_BYTES
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float2 *tbuf = lds + xs_slots + wave * (2 * RD_CHAN_KC * RD_CHAN_CPW);  // wave-private, double-buffered
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = row block
+    const int r = lane & 31, h = lane >> 5;
     const long t0 = (long)blockIdx.x * RD_CHAN_TT;
-    // stage samples n_base .. n_base + span - 1, n_base = D t0 - (T - 1)
+    const int grp = blockIdx.y;
+    // stage samples n_base .. n_base + span - 1, n_base = D t0 - (T - 1); a sample before the capture
+    // (or after it) is the byte 128 = value 0.  16-byte loads from an aligned start, four in flight.
     const long n_base = (long)D * t0 - (T - 1);
     const int span = (RD_CHAN_TT - 1) * D + T;
-    for (int i = threadIdx.x; i < span; i += blockDim.x) {
-        const long n = n_base + i;
-        float2 v = {0.0f, 0.0f};  // zero history before the capture (and zero padding after it)
-        if (n >= 0 && n < n_wide) {
-            const uint16_t iq = *(const uint16_t *)(wide + 2 * n);
-            v.x = ((float)(iq & 0xFF) - 127.4f) * (1.0f / 127.6f);
-            v.y = ((float)(iq >> 8) - 127.4f) * (1.0f / 127.6f);
-        }
-        xs[rd_chan_lds_index(i, D)] = v;
-    }
-    __syncthreads();
-    const long t = t0 + lane;
-    const int nwaves = blockDim.x >> 6;
-    for (int grp = blockIdx.y * nwaves + wave; grp < n_groups; grp += gridDim.y * nwaves) {  // wave-uniform
-        float ar[RD_CHAN_CPW], ai[RD_CHAN_CPW];
+    const long n_al = n_base - (((n_base % 8) + 8) % 8);
+    const int n_vec = (int)((n_base + span - n_al + 7) / 8);
+    for (int q0 = threadIdx.x; q0 < n_vec; q0 += 4 * blockDim.x) {
+        uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < RD_CHAN_CPW; q++) { ar[q] = 0.0f; ai[q] = 0.0f; }
-        // chunk c = taps k in [c KC, (c+1) KC) of this group's 4 channels: 64 float2 = 32 float4
-        const float4 *gsrc = (const float4 *)(taps + (size_t)grp * T * RD_CHAN_CPW);
-        const int n_chunks = T / RD_CHAN_KC;
-        float4 pre = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (lane < 32) pre = gsrc[lane];
-        // tap k reads relative sample j = T-1-k of time 0, D n + j of time n: padded index
-        // (D+1) n + j + j / D; j walks down, its quotient and remainder by D are kept in scalars
-        const float2 *xl = xs + (D + 1) * lane;
-        int j = T - 1, jq = (T - 1) / D, jr = (T - 1) % D;
-        for (int c = 0; c < n_chunks; c++) {
-            float2 *tb = tbuf + (c & 1) * (RD_CHAN_KC * RD_CHAN_CPW);
-            if (lane < 32) ((float4 *)tb)[lane] = pre;
-            if (c + 1 < n_chunks && lane < 32) pre = gsrc[(size_t)(c + 1) * 32 + lane];
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * blockDim.x;
+            const long n = n_al + 8L * q;
+            v[u] = uint4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+            if (q < n_vec) {
+                if (n >= 0 && n + 8 <= n_wide) {
+                    v[u] = *(const uint4 *)(wide + 2 * n);
+                } else {
+                    uint16_t e[8];
 #pragma unroll
-            for (int kk = 0; kk < RD_CHAN_KC; kk++) {
-                const float2 x = xl[j + jq];
-                const float4 g01 = ((const float4 *)tb)[kk * 2], g23 = ((const float4 *)tb)[kk * 2 + 1];  // broadcasts
-                const float gr[4] = {g01.x, g01.z, g23.x, g23.z}, gi[4] = {g01.y, g01.w, g23.y, g23.w};
-#pragma unroll
-                for (int q = 0; q < RD_CHAN_CPW; q++) {
-                    ar[q] = __builtin_fmaf(gr[q], x.x, ar[q]);
-                    ar[q] = __builtin_fmaf(-gi[q], x.y, ar[q]);
-                    ai[q] = __builtin_fmaf(gr[q], x.y, ai[q]);
-                    ai[q] = __builtin_fmaf(gi[q], x.x, ai[q]);
+                    for (int w = 0; w < 8; w++) e[w] = (n + w >= 0 && n + w < n_wide) ? *(const uint16_t *)(wide + 2 * (n + w)) : (uint16_t)0x8080;
+                    v[u] = uint4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
                 }
-                j--;
-                if (jr == 0) { jr = D - 1; jq--; } else jr--;
             }
         }
-        if (t < n_out) {
 #pragma unroll
-            for (int q = 0; q < RD_CHAN_CPW; q++) {
-                const int ch = grp * RD_CHAN_CPW + q;
-                if (ch >= n_ch) break;
-                // phase = -2 pi frac(shift t / Fo), the remainders exact in float64: shifts[] holds
-                // shift mod Fo in [0, Fo), Fo < 2^26, so (shift mod Fo)(t mod Fo) < 2^52
-                const double fo = (double)out_rate;
-                const double tm = rd_chan_mod((double)t, fo);
-                const double rm = rd_chan_mod((double)shifts[ch] * tm, fo);
-                float sn, cs;
-                sincospif(-2.0f * (float)(rm / fo), &sn, &cs);
-                const float zr = (ar[q] * cs - ai[q] * sn) * gain, zi = (ar[q] * sn + ai[q] * cs) * gain;
-                const float qr = fminf(fmaxf(rintf(zr * 127.6f + 127.4f), 0.0f), 255.0f);
-                const float qi = fminf(fmaxf(rintf(zi * 127.6f + 127.4f), 0.0f), 255.0f);
-                const uint16_t o = (uint16_t)((uint32_t)qr | ((uint32_t)qi << 8));
-                *(uint16_t *)(out + (size_t)ch * out_stride + 2 * t) = o;
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * blockDim.x;
+            if (q >= n_vec) continue;
+            const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const int i0 = (int)(n_al + 8L * q - n_base);
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const int i = i0 + w;
+                const uint32_t iq = (w4[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
+                // (I - 128, Q - 128) as a bf16 pair: exact, the upper halves of the two floats
+                const float fi = (float)(iq & 0xFF) - 128.0f, fq = (float)(iq >> 8) - 128.0f;
+                if (i >= 0 && i < span)
+                    ((uint32_t *)xs)[i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, fq), __builtin_bit_cast(uint32_t, fi), 0x07060302u);
             }
+        }
+    }
+    // A chunk c = K steps 2c, 2c+1 of this group: 2 * RD_CHAN_Q_BYTES = 24 KiB = 1536 uint4, six per thread
+    constexpr int CH4 = RD_CHAN_Q_BYTES / 16;
+    const uint4 *asrc = amat + (size_t)grp * (T / 8) * (RD_CHAN_Q_BYTES / 16);
+    const int n_chunks = T / RD_CHAN_KC;
+    // chunk 0 goes to LDS directly; chunks 1 .. NPF wait in registers (an L2 round trip is longer
+    // than one chunk's 24 MFMAs per wave: with one chunk in flight the loop waited on it)
+    constexpr int NPF = RD_CHAN_NPF;
+    {
+        uint4 first[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) first[u] = asrc[u * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 3; u++) abuf[u * 256 + threadIdx.x] = first[u];
+    }
+    uint4 pre[NPF][3];
+#pragma unroll
+    for (int s = 0; s < NPF; s++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            pre[s][u] = (s + 1 < n_chunks) ? asrc[(size_t)(s + 1) * CH4 + u * 256 + threadIdx.x] : uint4{0, 0, 0, 0};
+    __syncthreads();
+
+    rd_f32x16 acc[RD_CHAN_TB];
+#pragma unroll
+    for (int b = 0; b < RD_CHAN_TB; b++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[b][e] = 0.0f;
+    // B fragment of (time block tb, K step q): window samples 8q + 4h .. +3 of column 32 tb + r
+    const uint8_t *xl = xs + 4 * (D * r + 4 * h);
+    for (int c0 = 0; c0 < n_chunks; c0 += NPF) {
+#pragma unroll
+        for (int s = 0; s < NPF; s++) {
+            const int c = c0 + s;
+            if (c >= n_chunks) break;  // uniform
+            const uint4 *ab = abuf + (c & 1) * CH4;
+            const int q = c;
+            rd_bf16x8 a[3];
+#pragma unroll
+            for (int term = 0; term < 3; term++)
+                a[term] = __builtin_bit_cast(rd_bf16x8, ab[(term * RD_CHAN_RBG + wave) * 64 + lane]);
+#pragma unroll
+            for (int tb = 0; tb < RD_CHAN_TB; tb++) {
+                const rd_bf16x8 bfrag = __builtin_bit_cast(rd_bf16x8, *(const uint4 *)(xl + 4 * (D * 32 * tb + 8 * q)));
+#pragma unroll
+                for (int term = 0; term < 3; term++)
+                    acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[term], bfrag, acc[tb], 0, 0, 0);
+            }
+            if (c + 1 < n_chunks) {
+                uint4 *an = abuf + ((c + 1) & 1) * CH4;
+#pragma unroll
+                for (int u = 0; u < 3; u++) an[u * 256 + threadIdx.x] = pre[s][u];
+            }
+            if (c + 1 + NPF < n_chunks) {
+#pragma unroll
+                for (int u = 0; u < 3; u++) pre[s][u] = asrc[(size_t)(c + 1 + NPF) * CH4 + u * 256 + threadIdx.x];
+            }
+            __syncthreads();
+        }
+    }
+    // epilogue: register e of tile tb holds row (e & 3) + 8 (e >> 2) + 4 h, column r; rows 2i, 2i+1 =
+    // (re, im) of channel 16 (4 grp + wave) + i
+    const float scale = gain * (1.0f / 127.6f);
+#pragma unroll
+    for (int tb = 0; tb < RD_CHAN_TB; tb++) {
+        const long t = t0 + 32 * tb + r;
+        if (t >= n_out) continue;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int ch = 16 * (RD_CHAN_RBG * grp + wave) + (row >> 1);
+            if (ch >= n_ch) continue;
+            const float2 d0 = dc[(size_t)ch * (RD_CHAN_EARLY + 1) + (t < n_early ? (int)t : RD_CHAN_EARLY)];
+            const float re = acc[tb][e] + d0.x, im = acc[tb][e + 1] + d0.y;
+            // phase = -2 pi frac(shift t / Fo), the remainders exact in float64
+            const double fo = (double)out_rate;
+            const double tm = rd_chan_mod((double)t, fo);
+            const double rm = rd_chan_mod((double)shifts[ch] * tm, fo);
+            float sn, cs;
+            sincospif(-2.0f * (float)(rm / fo), &sn, &cs);
+            const float zr = (re * cs - im * sn) * scale, zi = (re * sn + im * cs) * scale;
+            const float qr = fminf(fmaxf(rintf(zr * 127.6f + 127.4f), 0.0f), 255.0f);
+            const float qi = fminf(fmaxf(rintf(zi * 127.6f + 127.4f), 0.0f), 255.0f);
+            const uint16_t o = (uint16_t)((uint32_t)qr | ((uint32_t)qi << 8));
+            *(uint16_t *)(out + (size_t)ch * out_stride + 2 * t) = o;
         }
     }
 }
@@ -168,43 +242,94 @@ __global__ __launch_bounds__(64 * RD_CHAN_MAX_WAVES) void k_channelize(const uin
         if (e_ != hipSuccess) return rd_fail_msg(RD_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_));      \
     } while (0)
 
+static uint16_t bf16_rn(double v) {  // round to nearest even bf16
+    float f = (float)v;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static double bf16_val(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return (double)f;
+}
+
 extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, const int64_t *shift_hz, rd_chan **out) {
     if (!cfg || !taps || !shift_hz || !out) return rd_fail_msg(RD_ERR_ARG, "null argument");
-    if (cfg->decim < 1 || cfg->decim > 4096 || cfg->n_taps < 1 || cfg->n_taps > 8192 || cfg->n_channels < 1 ||
-        cfg->n_channels > 4096 || cfg->out_rate < 1 || cfg->out_rate >= (1 << 26) || !(cfg->gain > 0.0))
-        return rd_fail_msg(RD_ERR_ARG, "channelizer config out of range");
+    if (cfg->decim < 4 || cfg->decim > 4096 || cfg->decim % 4 || cfg->n_taps < 1 || cfg->n_taps > 8192 ||
+        cfg->n_channels < 1 || cfg->n_channels > 4096 || cfg->out_rate < 1 || cfg->out_rate >= (1 << 26) ||
+        !(cfg->gain > 0.0))
+        return rd_fail_msg(RD_ERR_ARG, "channelizer config out of range (decim: a multiple of 4)");
     const int t_pad = (cfg->n_taps + RD_CHAN_KC - 1) / RD_CHAN_KC * RD_CHAN_KC;
-    const size_t lds = ((size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad);
-    if ((lds + lds / cfg->decim + 2 + RD_CHAN_MAX_WAVES * 2 * RD_CHAN_KC * RD_CHAN_CPW) * sizeof(float2) > 160 * 1024)
-        return rd_fail_msg(RD_ERR_ARG, "decim x 63 + n_taps samples do not fit the 160 KiB LDS");
+    const size_t span = (size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad;
+    if (4 * span + 16 + 2 * RD_CHAN_Q_BYTES > 160 * 1024)
+        return rd_fail_msg(RD_ERR_ARG, "decim x 255 + n_taps samples do not fit the 160 KiB LDS");
+    const int n_early = (t_pad - 1 + cfg->decim - 1) / cfg->decim;
+    if (n_early > RD_CHAN_EARLY) return rd_fail_msg(RD_ERR_ARG, "n_taps / decim too large");
     rd_chan *h = new rd_chan();
     h->cfg = *cfg;
     const int T = cfg->n_taps;
     h->t_pad = t_pad;
-    h->n_ch_pad = (cfg->n_channels + RD_CHAN_CPW - 1) / RD_CHAN_CPW * RD_CHAN_CPW;
-    h->h_taps.assign((size_t)h->n_ch_pad * t_pad * 2, 0.0f);
+    h->n_early = n_early;
+    h->n_groups = (cfg->n_channels + 16 * RD_CHAN_RBG - 1) / (16 * RD_CHAN_RBG);
+    const int n_q = t_pad / 8;
+    h->h_amat.assign((size_t)h->n_groups * n_q * (RD_CHAN_Q_BYTES / 2), 0);
+    h->h_dc.assign((size_t)cfg->n_channels * (RD_CHAN_EARLY + 1) * 2, 0.0f);
     h->shifts.resize(cfg->n_channels);  // shift mod Fo in [0, Fo): all the output phasor needs
     for (int c = 0; c < cfg->n_channels; c++) h->shifts[c] = ((shift_hz[c] % cfg->out_rate) + cfg->out_rate) % cfg->out_rate;
     const double wide_rate = (double)cfg->out_rate * cfg->decim;
-    for (int c = 0; c < cfg->n_channels; c++)
-        for (int k = 0; k < T; k++) {
+    std::vector<double> gr(t_pad), gi(t_pad);
+    for (int c = 0; c < cfg->n_channels; c++) {
+        for (int k = 0; k < t_pad; k++) {
+            gr[k] = gi[k] = 0.0;
+            if (k >= T) continue;
             // g_c[k] = h[k] e^{+j 2 pi shift k / Fw}; the phase through an exact integer remainder
             const __int128 prod = (__int128)shift_hz[c] * k;
             const long fw = (long)cfg->out_rate * cfg->decim;
             long r = (long)(prod % fw);
             if (r < 0) r += fw;
             const double ph = 2.0 * M_PI * ((double)r / wide_rate);
-            const size_t at = ((((size_t)(c / RD_CHAN_CPW) * t_pad + k) * RD_CHAN_CPW) + c % RD_CHAN_CPW) * 2;
-            h->h_taps[at] = (float)(taps[k] * cos(ph));
-            h->h_taps[at + 1] = (float)(taps[k] * sin(ph));
+            gr[k] = (double)(float)(taps[k] * cos(ph));  // the fp32 taps are the definition's taps on the device
+            gi[k] = (double)(float)(taps[k] * sin(ph));
         }
+        // DC term: lut(b) = (b - 128 + 0.6) / 127.6; output t sees taps k <= D t (zero history before)
+        double sr = 0.0, si = 0.0;
+        int kdone = 0;
+        for (int t = 0; t <= RD_CHAN_EARLY; t++) {
+            const long kmax = t < RD_CHAN_EARLY ? (long)cfg->decim * t : (long)t_pad - 1;
+            for (; kdone < t_pad && kdone <= kmax; kdone++) { sr += gr[kdone]; si += gi[kdone]; }
+            // 0.6 (1 + j)(sr + j si) = 0.6 ((sr - si) + j (sr + si))
+            h->h_dc[((size_t)c * (RD_CHAN_EARLY + 1) + t) * 2] = (float)(0.6 * (sr - si));
+            h->h_dc[((size_t)c * (RD_CHAN_EARLY + 1) + t) * 2 + 1] = (float)(0.6 * (sr + si));
+        }
+        // rows 2c (re) and 2c+1 (im); kappa = 2 i + comp, window sample i = t_pad - 1 - k
+        const int grp = c / (16 * RD_CHAN_RBG), rb = (c / 16) % RD_CHAN_RBG, r0 = 2 * (c % 16);
+        for (int i = 0; i < t_pad; i++) {
+            const int k = t_pad - 1 - i;
+            const int q = i / 8, hh = (i % 8) / 4, j0 = 2 * (i % 4);  // lane half and element pair of this sample
+            for (int part = 0; part < 2; part++)
+                for (int comp = 0; comp < 2; comp++) {
+                    const double a = part == 0 ? (comp == 0 ? gr[k] : -gi[k]) : (comp == 0 ? gi[k] : gr[k]);
+                    const uint16_t hi = bf16_rn(a), mid = bf16_rn(a - bf16_val(hi)),
+                                   lo = bf16_rn(a - bf16_val(hi) - bf16_val(mid));
+                    const uint16_t term[3] = {hi, mid, lo};
+                    const int lane = 32 * hh + r0 + part;
+                    for (int tm = 0; tm < 3; tm++) {
+                        const size_t at = (((((size_t)grp * n_q + q) * 3 + tm) * RD_CHAN_RBG + rb) * 64 + lane) * 8 + j0 + comp;
+                        h->h_amat[at] = term[tm];
+                    }
+                }
+        }
+    }
     *out = h;
     return RD_OK;
 }
 
 extern "C" void rd_chan_destroy(rd_chan *h) {
     if (!h) return;
-    if (h->dev_ready) { hipFree(h->d_taps); hipFree(h->d_shifts); hipFree(h->d_wide); }
+    if (h->dev_ready) { hipFree(h->d_amat); hipFree(h->d_dc); hipFree(h->d_shifts); hipFree(h->d_wide); }
     delete h;
 }
 
@@ -212,8 +337,10 @@ static int chan_alloc(rd_chan *h, size_t n_wide) {
     int rc = rd_ensure_device_public();
     if (rc) return rc;
     if (!h->dev_ready) {
-        CHK(hipMalloc(&h->d_taps, h->h_taps.size() * sizeof(float)));
-        CHK(hipMemcpy(h->d_taps, h->h_taps.data(), h->h_taps.size() * sizeof(float), hipMemcpyHostToDevice));
+        CHK(hipMalloc(&h->d_amat, h->h_amat.size() * sizeof(uint16_t)));
+        CHK(hipMemcpy(h->d_amat, h->h_amat.data(), h->h_amat.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        CHK(hipMalloc(&h->d_dc, h->h_dc.size() * sizeof(float)));
+        CHK(hipMemcpy(h->d_dc, h->h_dc.data(), h->h_dc.size() * sizeof(float), hipMemcpyHostToDevice));
         CHK(hipMalloc(&h->d_shifts, h->shifts.size() * sizeof(int64_t)));
         CHK(hipMemcpy(h->d_shifts, h->shifts.data(), h->shifts.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         h->dev_ready = true;
@@ -256,21 +383,14 @@ extern "C" int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_s
         return rd_fail_msg(RD_ERR_ARG, "destination stride too small for n_out samples");
     const int T = h->t_pad, D = h->cfg.decim;
     const size_t span = (size_t)(RD_CHAN_TT - 1) * D + T;
-    const int groups = h->n_ch_pad / RD_CHAN_CPW;
-    const int waves = groups < RD_CHAN_MAX_WAVES ? groups : RD_CHAN_MAX_WAVES;
-    const size_t xs_slots = (span + span / D + 2) & ~(size_t)1;  // float2 slots, 16-byte aligned end
-    const size_t lds = (xs_slots + (size_t)waves * 2 * RD_CHAN_KC * RD_CHAN_CPW) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CHK(hipFuncSetAttribute((const void *)k_channelize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const size_t xs_bytes = (4 * span + 15) & ~(size_t)15;
+    const size_t lds = xs_bytes + 2 * RD_CHAN_Q_BYTES;
+    CHK(hipFuncSetAttribute((const void *)k_channelize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned gx = (unsigned)((n_out + RD_CHAN_TT - 1) / RD_CHAN_TT);
-    const unsigned gy = (unsigned)((groups + waves - 1) / waves);
-    hipLaunchKernelGGL(k_channelize, dim3(gx, gy), dim3(64 * waves), lds, (hipStream_t)hip_stream, h->d_wide,
-                       (long)h->wide_n, (const float2 *)h->d_taps, h->d_shifts, T, D, h->cfg.n_channels, groups,
-                       (long)h->cfg.out_rate, (float)h->cfg.gain, (long)n_out, (uint8_t *)dst_dev, dst_stream_stride,
-                       (int)xs_slots);
+    hipLaunchKernelGGL(k_channelize, dim3(gx, (unsigned)h->n_groups), dim3(256), lds, (hipStream_t)hip_stream, h->d_wide,
+                       (long)h->wide_n, (const uint4 *)h->d_amat, (const float2 *)h->d_dc, h->d_shifts, T, D,
+                       h->cfg.n_channels, h->n_early, (long)h->cfg.out_rate, (float)h->cfg.gain, (long)n_out,
+                       (uint8_t *)dst_dev, dst_stream_stride, (int)xs_bytes);
     CHK(hipGetLastError());
     return RD_OK;
 }

@@ -107,6 +107,8 @@ def test_channelizer_argument_checks_and_no_fallback():
         channelizer.Channelizer([914963100], gain=0.0)
     with pytest.raises(ValueError):
         channelizer.Channelizer([914963100], taps=np.ones(9000))                    # more taps than the kernel stages
+    with pytest.raises(ValueError):
+        channelizer.Channelizer([914963100], decim=98)                              # decimation not a multiple of 4
     cz = channelizer.Channelizer()                                                  # host state only
     assert cz.n_channels == 51 and cz.shift_hz[25] == 67200 and cz.taps.size == 512
     if _lib.lib().rd_device_count() > 0:
