@@ -26,19 +26,18 @@
 // three bf16 terms (hi + mid + lo reproduces 24 bits), i.e. three MFMAs per tile and K step into the
 // same fp32 accumulator: products are exact, sums are fp32 - the same error class as an fp32 chain.
 // 8 T flops per output: 113 GFLOP for one second of 51 channels; HBM traffic is 81 MB.
-// A workgroup = 4 waves = 256 output times x a group of 4 row blocks (64 channels); wave w owns row
-// block w and all eight 32-time blocks (8 accumulator tiles = 128 registers).  The 255 D + T input
-// samples are staged once in LDS as bf16 pairs (I - 128, Q - 128) - 104 KiB - so a B fragment is one
-// aligned ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free); the A operand streams from
-// L2 through a double-buffered 12-KiB LDS chunk per K step, fetched two steps ahead in registers.
-// Per K step a wave issues 11 LDS reads and 24 MFMAs.
-// Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.36 ms = 2780x real time; the
-// fp32 VALU kernel this replaced took 0.88 ms (64 TFLOP/s, bound by the CU's LDS pipe: every fma
-// needed 2.5 bytes from LDS), an fp32-MFMA version 0.84 ms.  Steps on the way: converting the B
-// bytes per fragment in each wave 0.55 ms (one wave per SIMD cannot hide ~25 VALU instructions per
-// three MFMAs), A chunks one step ahead only 0.55 -> 0.46 with two.  Left on the table: the MFMA
-// pipe is busy a quarter of the time (64 barriers per workgroup, a fifth round for 1056 tiles on
-// 256 CUs at one workgroup per CU).
+// A workgroup = 4 waves = 128 output times x a group of 4 row blocks (64 channels); wave w owns row
+// block w and the four 32-time blocks (4 accumulator tiles).  The 127 D + T input samples are staged
+// once in LDS as bf16 pairs (I - 128, Q - 128) - 52 KiB - so a B fragment is one aligned
+// ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free); the A operand streams from L2
+// through a double-buffered 12-KiB LDS chunk per K step, fetched two steps ahead in registers.
+// Two workgroups fit a CU, so one's barrier (one per K step) hides behind the other's MFMAs.
+// Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.27 ms = 3680x real time.
+// On the way: fp32 VALU kernel 0.88 ms (64 TFLOP/s, bound by the CU's LDS pipe: every fma needed
+// 2.5 bytes from LDS), fp32 MFMA 0.84 ms, bf16 MFMA with the B bytes converted per fragment in
+// each wave 0.55 ms (one wave per SIMD cannot hide ~25 VALU instructions per three MFMAs), A
+// chunks two steps ahead instead of one 0.55 -> 0.46, samples pre-converted in LDS 0.36, 128
+// instead of 256 output times per workgroup (two workgroups per CU, 2112 tiles) 0.27.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,7 +51,7 @@
 extern int rd_fail_msg(int code, const char *fmt, ...);  // rd_api.hip: sets rd_last_error
 extern int rd_ensure_device_public(void);
 
-#define RD_CHAN_TB 8                        // 32-time blocks per wave
+#define RD_CHAN_TB 4                        // 32-time blocks per wave
 #define RD_CHAN_TT (32 * RD_CHAN_TB)        // output times per workgroup
 #define RD_CHAN_RBG 4                       // row blocks (32 rows = 16 channels) per workgroup: one per wave
 #define RD_CHAN_KC 8                        // window samples per staged A chunk (one K step)
