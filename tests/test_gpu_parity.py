@@ -206,6 +206,31 @@ def test_soak_small_configs_dense_duplicates(dsp, batchmod):
     assert n >= 768 and at_edge >= 5
 
 
+def test_batch_api_call_orders(dsp, batchmod, golden_streams):
+    """run twice before fetching, results fetched twice, parse switched on between runs: the
+    packets are those of the reference every time (counter sets alternate per run; records of a
+    run stay readable until the next run)."""
+    cfg = prod_cfg(dsp)
+    raw = synth.synth_streams(range(4))
+    bd = batchmod.BatchDemodulator(cfg, 4, 33)
+    bd.upload(raw)
+    bd.run()
+    bd.run()                      # first run's results dropped, never mixed into the second's
+    a = bd.results()
+    b = bd.results()
+    assert np.array_equal(a, b)
+    for s in range(4):
+        assert_calls_equal(bd.packets()[s], dense_calls(golden_streams[str(s)]["calls"], 33))
+    bd.set_parse(True)
+    bd.run()
+    assert np.array_equal(bd.results(), a)
+    assert len(bd.parsed()) == 4  # one CRC-valid message per stream
+    bd.set_parse(False)
+    for _ in range(3):
+        bd.run()
+        assert np.array_equal(bd.results(), a)
+
+
 def test_batch_degenerate_inputs_take_the_exact_path(dsp, batchmod):
     """Low-amplitude and saturated inputs put most runs inside the guard band: the guard
     list overflows and every run is re-evaluated exactly.  Bits must still match."""
