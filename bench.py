@@ -77,7 +77,19 @@ def cpu_baseline(uniq: np.ndarray, budget_s: float = 12.0):
     dt = time.perf_counter() - t0
     return {"value": round(samples * reps / dt / 1e6, 2), "unit": "MS/s", "cores": th, "kind": "port",
             "sample": f"{work.shape[0]} streams ({uniq.shape[0]} unique) x {work.shape[1] // 2} samples, {reps} passes "
-                      f"({samples * reps / 1e6:.0f} MS, {dt:.1f} s wall), best of 1..{ncpu} threads on {ncpu} host cpus"}
+                      f"({samples * reps / 1e6:.0f} MS, {dt:.1f} s wall), best of 1..{ncpu} threads on {ncpu} host cpus "
+                      f"({_cpu_model()})"}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown cpu"
 
 
 def main():
