@@ -266,10 +266,11 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
             const uint32_t s = widx / (uint32_t)lay.bits_stride;
             const uint32_t run = widx - s * (uint32_t)lay.bits_stride;
             v.base = lay.iq + (size_t)s * lay.stream_stride;
-            // Tried and measured no faster: a per-lane "lowest flagged group first" loop (25 % slower)
-            // and expanding the entries into one (word, group) item per lane through LDS (3.6x fewer
-            // instructions, same 50 us): the kernel waits on ~0.6 M scattered 64-128 B reads of the
-            // IQ stream, not on the ALU, and the static loop lets the four iterations' loads overlap.
+            // Where the 39 us go (ablations): launch + list read 9, byte stores 6.5, IQ reads 11,
+            // float64 arithmetic 14.  Tried and measured no faster: a per-lane "lowest flagged group
+            // first" loop (25 % slower), expanding the entries into one (word, group) item per lane
+            // through LDS (3.6x fewer instructions, same time), reading the run's window from a
+            // scratch area the demod kernel fills from its registers (same time; demod kernel +6 %).
             for (int g = 0; g < RD_GROUPS; g++) {
                 if (!((e >> g) & 1)) continue;
                 const long t0 = (long)run * RD_RUN + g * RD_GROUP;
