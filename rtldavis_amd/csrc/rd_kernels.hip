@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
             // Where the 39 us go (ablations): launch + list read 9, byte stores 6.5, IQ reads 11,
             // float64 arithmetic 14.  Tried and measured no faster: a per-lane "lowest flagged group
             // first" loop (25 % slower), expanding the entries into one (word, group) item per lane
-            // through LDS (3.6x fewer instructions, same time), reading the run's window from a
+            // through LDS (-2 us), reading the run's window from a
             // scratch area the demod kernel fills from its registers (same time; demod kernel +6 %).
             for (int g = 0; g < RD_GROUPS; g++) {
                 if (!((e >> g) & 1)) continue;
