@@ -28,16 +28,17 @@
 // 8 T flops per output: 113 GFLOP for one second of 51 channels; HBM traffic is 81 MB.
 // A workgroup = 4 waves = 128 output times x a group of 4 row blocks (64 channels); wave w owns row
 // block w and the four 32-time blocks (4 accumulator tiles).  The 127 D + T input samples are staged
-// once in LDS as bf16 pairs (I - 128, Q - 128) - 52 KiB - so a B fragment is one aligned
-// ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free); the A operand streams from L2
-// through a double-buffered 12-KiB LDS chunk per K step, fetched two steps ahead in registers.
-// Two workgroups fit a CU, so one's barrier (one per K step) hides behind the other's MFMAs.
-// Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.27 ms = 3680x real time.
+// once in LDS as bf16 pairs (I - 128, Q - 128) - 52 KiB, three workgroups per CU - so a B fragment is
+// one aligned ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free).  A wave only needs its
+// own row block's A fragments (3 terms x 16 bytes per lane and K step): they come straight from L2
+// into registers two K steps ahead; the main loop has no barrier.
+// Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.25 ms = 4000x real time.
 // On the way: fp32 VALU kernel 0.88 ms (64 TFLOP/s, bound by the CU's LDS pipe: every fma needed
 // 2.5 bytes from LDS), fp32 MFMA 0.84 ms, bf16 MFMA with the B bytes converted per fragment in
 // each wave 0.55 ms (one wave per SIMD cannot hide ~25 VALU instructions per three MFMAs), A
-// chunks two steps ahead instead of one 0.55 -> 0.46, samples pre-converted in LDS 0.36, 128
-// instead of 256 output times per workgroup (two workgroups per CU, 2112 tiles) 0.27.
+// through a shared LDS chunk two steps ahead instead of one 0.55 -> 0.46, samples pre-converted in
+// LDS 0.36, 128 instead of 256 output times per workgroup 0.27, A per wave from L2 without LDS or
+// barriers 0.25.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,7 +55,7 @@ extern int rd_ensure_device_public(void);
 #define RD_CHAN_TB 4                        // 32-time blocks per wave
 #define RD_CHAN_TT (32 * RD_CHAN_TB)        // output times per workgroup
 #define RD_CHAN_RBG 4                       // row blocks (32 rows = 16 channels) per workgroup: one per wave
-#define RD_CHAN_KC 8                        // window samples per staged A chunk (one K step)
+#define RD_CHAN_KC 8                        // window samples per K step (taps are padded to a multiple)
 #define RD_CHAN_Q_BYTES (3 * RD_CHAN_RBG * 64 * 16)  // A bytes per K step: 3 terms x 4 row blocks x 64 lanes x 16 B
 #ifndef RD_CHAN_NPF
 #define RD_CHAN_NPF 2                       // A chunks in flight in registers
@@ -96,7 +97,6 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
                                                     size_t out_stride, int xs_bytes) {
     extern __shared__ uint8_t lds[];
     uint8_t *xs = lds;                            // window samples 0 .. span-1 as bf16 pairs (I - 128, Q - 128)
-    uint4 *abuf = (uint4 *)(lds + xs_bytes);      // 2 chunks x 2 K steps x RD_CHAN_Q_BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = row block
     const int r = lane & 31, h = lane >> 5;
@@ -144,27 +144,19 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
             }
         }
     }
-    // A chunk c = K steps 2c, 2c+1 of this group: 2 * RD_CHAN_Q_BYTES = 24 KiB = 1536 uint4, six per thread
-    constexpr int CH4 = RD_CHAN_Q_BYTES / 16;
     const uint4 *asrc = amat + (size_t)grp * (T / 8) * (RD_CHAN_Q_BYTES / 16);
     const int n_chunks = T / RD_CHAN_KC;
-    // chunk 0 goes to LDS directly; chunks 1 .. NPF wait in registers (an L2 round trip is longer
-    // than one chunk's 24 MFMAs per wave: with one chunk in flight the loop waited on it)
+    // A wave only ever needs ITS row block's A fragments (3 terms x 16 bytes per lane and K step):
+    // they come straight from L2 into registers, NPF steps ahead - no LDS, no barrier in the loop.
     constexpr int NPF = RD_CHAN_NPF;
-    {
-        uint4 first[3];
-#pragma unroll
-        for (int u = 0; u < 3; u++) first[u] = asrc[u * 256 + threadIdx.x];
-#pragma unroll
-        for (int u = 0; u < 3; u++) abuf[u * 256 + threadIdx.x] = first[u];
-    }
+    const uint4 *amine = asrc + wave * 64 + lane;   // + (q * 3 + term) * RD_CHAN_RBG * 64
     uint4 pre[NPF][3];
 #pragma unroll
     for (int s = 0; s < NPF; s++)
 #pragma unroll
-        for (int u = 0; u < 3; u++)
-            pre[s][u] = (s + 1 < n_chunks) ? asrc[(size_t)(s + 1) * CH4 + u * 256 + threadIdx.x] : uint4{0, 0, 0, 0};
-    __syncthreads();
+        for (int term = 0; term < 3; term++)
+            pre[s][term] = amine[(size_t)((s < n_chunks ? s : n_chunks - 1) * 3 + term) * (RD_CHAN_RBG * 64)];
+    __syncthreads();  // the staged samples
 
     rd_f32x16 acc[RD_CHAN_TB];
 #pragma unroll
@@ -176,14 +168,17 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
     for (int c0 = 0; c0 < n_chunks; c0 += NPF) {
 #pragma unroll
         for (int s = 0; s < NPF; s++) {
-            const int c = c0 + s;
-            if (c >= n_chunks) break;  // uniform
-            const uint4 *ab = abuf + (c & 1) * CH4;
-            const int q = c;
+            const int q = c0 + s;
+            if (q >= n_chunks) break;  // uniform
             rd_bf16x8 a[3];
 #pragma unroll
-            for (int term = 0; term < 3; term++)
-                a[term] = __builtin_bit_cast(rd_bf16x8, ab[(term * RD_CHAN_RBG + wave) * 64 + lane]);
+            for (int term = 0; term < 3; term++) a[term] = __builtin_bit_cast(rd_bf16x8, pre[s][term]);
+            {   // refill this slot with step q + NPF (the last steps refetch the final one: a static
+                // number of loads in flight)
+                const int qn = (q + NPF < n_chunks) ? q + NPF : n_chunks - 1;
+#pragma unroll
+                for (int term = 0; term < 3; term++) pre[s][term] = amine[(size_t)(qn * 3 + term) * (RD_CHAN_RBG * 64)];
+            }
 #pragma unroll
             for (int tb = 0; tb < RD_CHAN_TB; tb++) {
                 const rd_bf16x8 bfrag = __builtin_bit_cast(rd_bf16x8, *(const uint4 *)(xl + 4 * (D * 32 * tb + 8 * q)));
@@ -191,16 +186,6 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
                 for (int term = 0; term < 3; term++)
                     acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[term], bfrag, acc[tb], 0, 0, 0);
             }
-            if (c + 1 < n_chunks) {
-                uint4 *an = abuf + ((c + 1) & 1) * CH4;
-#pragma unroll
-                for (int u = 0; u < 3; u++) an[u * 256 + threadIdx.x] = pre[s][u];
-            }
-            if (c + 1 + NPF < n_chunks) {
-#pragma unroll
-                for (int u = 0; u < 3; u++) pre[s][u] = asrc[(size_t)(c + 1 + NPF) * CH4 + u * 256 + threadIdx.x];
-            }
-            __syncthreads();
         }
     }
     // epilogue: register e of tile tb holds row (e & 3) + 8 (e >> 2) + 4 h, column r; rows 2i, 2i+1 =
@@ -263,7 +248,7 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
         return rd_fail_msg(RD_ERR_ARG, "channelizer config out of range (decim: a multiple of 4)");
     const int t_pad = (cfg->n_taps + RD_CHAN_KC - 1) / RD_CHAN_KC * RD_CHAN_KC;
     const size_t span = (size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad;
-    if (4 * span + 16 + 2 * RD_CHAN_Q_BYTES > 160 * 1024)
+    if (4 * span + 16 > 160 * 1024)
         return rd_fail_msg(RD_ERR_ARG, "decim x 255 + n_taps samples do not fit the 160 KiB LDS");
     const int n_early = (t_pad - 1 + cfg->decim - 1) / cfg->decim;
     if (n_early > RD_CHAN_EARLY) return rd_fail_msg(RD_ERR_ARG, "n_taps / decim too large");
@@ -383,7 +368,7 @@ extern "C" int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_s
     const int T = h->t_pad, D = h->cfg.decim;
     const size_t span = (size_t)(RD_CHAN_TT - 1) * D + T;
     const size_t xs_bytes = (4 * span + 15) & ~(size_t)15;
-    const size_t lds = xs_bytes + 2 * RD_CHAN_Q_BYTES;
+    const size_t lds = xs_bytes;
     CHK(hipFuncSetAttribute((const void *)k_channelize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned gx = (unsigned)((n_out + RD_CHAN_TT - 1) / RD_CHAN_TT);
     hipLaunchKernelGGL(k_channelize, dim3(gx, (unsigned)h->n_groups), dim3(256), lds, (hipStream_t)hip_stream, h->d_wide,
