@@ -359,21 +359,40 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
     const uint32_t nwave_groups = (uint32_t)n_streams * wgps;
     const uint32_t nwaves = gridDim.x * RD_SEARCH_WAVES;
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * RD_SEARCH_WAVES + (threadIdx.x >> 6));
-    // RD_SEARCH_UNROLL wave-groups per trip: all their loads are issued before the first is used
-    // (the kernel is a chain of load latencies, not of ALU work)
+    // RD_SEARCH_UNROLL wave-groups per trip: all their loads are issued before the first is used.
+    // Everything per lane is 32-bit (positions and word indices of one stream fit), the stream /
+    // group split of a wave-group is carried in scalars (no division in the loop): half of this
+    // kernel's instructions used to be 64-bit index arithmetic and bounds tests.
     constexpr int NW = S_ > 0 ? ((RD_SEARCH_OUT + ((P_ > 0 ? P_ - 1 : 0) * (S_ > 0 ? S_ : 1) + 31) / 32 + 1 + 3) / 4) * 4 : 4;
+    const int nwords_i = (int)nwords, gps = (int)groups_per_stream, plo = (int)p_lo, phi = (int)p_hi;
+    const int base_i = (int)base, base_w = (int)(base >> 5);
+    // 16-byte loads need every stream's words and the first word index 16-byte aligned
+    const bool aligned16 = (bits_stride % 4 == 0) && (base_w % 4 == 0) && ((size_t)bits % 16 == 0);
+    // wave-group wg = s * wgps + rem; a trip advances by step = nwaves * UNROLL, a slot by nwaves
+    const uint32_t dq_n = nwaves / wgps, dr_n = nwaves % wgps;
+    uint32_t s0 = wave0 / wgps, rem0 = wave0 % wgps;
     for (uint32_t wg0 = wave0; wg0 < nwave_groups; wg0 += nwaves * RD_SEARCH_UNROLL) {
         uint32_t r[RD_SEARCH_UNROLL][NW];
+        uint32_t su[RD_SEARCH_UNROLL], remu[RD_SEARCH_UNROLL];
+        {
+            uint32_t sx = s0, rx = rem0;
+#pragma unroll
+            for (int u = 0; u < RD_SEARCH_UNROLL; u++) {
+                su[u] = sx; remu[u] = rx;
+                sx += dq_n; rx += dr_n;
+                if (rx >= wgps) { rx -= wgps; sx++; }
+            }
+            s0 = sx; rem0 = rx;  // the next trip's first slot
+        }
         if constexpr (S_ > 0) {
 #pragma unroll
             for (int u = 0; u < RD_SEARCH_UNROLL; u++) {
                 const uint32_t wg = wg0 + u * nwaves;
                 if (wg >= nwave_groups) break;  // wave-uniform
-                const uint32_t s = wg / wgps;
-                const long gi = (long)(wg - s * wgps) * 64 + lane;
-                const uint32_t *w = bits + (size_t)s * bits_stride;
-                const long w0 = (base + 32L * RD_SEARCH_OUT * gi) >> 5;  // multiple of 4 words
-                if (gi < groups_per_stream && w0 >= 0 && w0 + NW <= nwords && (((size_t)(w + w0)) & 15) == 0) {
+                const int gi = (int)remu[u] * 64 + lane;
+                const uint32_t *w = bits + (size_t)su[u] * bits_stride;
+                const int w0 = base_w + RD_SEARCH_OUT * gi;
+                if (aligned16 && gi < gps && w0 >= 0 && w0 + NW <= nwords_i) {
                     // interior: NW/4 coalesced 16-byte loads (lane i reads bytes 16i.. of the wave's span)
 #pragma unroll
                     for (int j = 0; j < NW / 4; j++) {
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < NW; j++) r[u][j] = gi < groups_per_stream ? rd_word_at(w, nwords, w0 + j) : 0u;
+                    for (int j = 0; j < NW; j++) r[u][j] = gi < gps ? rd_word_at(w, nwords, (long)w0 + j) : 0u;
                 }
             }
         }
@@ -390,12 +409,12 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
         for (int u = 0; u < RD_SEARCH_UNROLL; u++) {
             const uint32_t wg = wg0 + u * nwaves;
             if (wg >= nwave_groups) break;  // wave-uniform
-            const uint32_t s = wg / wgps;
-            const long gi = (long)(wg - s * wgps) * 64 + lane;
+            const uint32_t s = su[u];
+            const int gi = (int)remu[u] * 64 + lane;
             uint32_t m[RD_SEARCH_OUT] = {0, 0, 0, 0};
-            long p0 = 0;
-            if (gi < groups_per_stream) {
-                p0 = base + 32L * RD_SEARCH_OUT * gi;
+            int p0 = 0;
+            if (gi < gps) {
+                p0 = base_i + 32 * RD_SEARCH_OUT * gi;
                 const uint32_t *w = bits + (size_t)s * bits_stride;
 #pragma unroll
                 for (int o = 0; o < RD_SEARCH_OUT; o++) m[o] = 0xFFFFFFFFu;
@@ -428,14 +447,17 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
                         const uint32_t x = ((cfg.pre_mask >> k) & 1) ? 0u : 0xFFFFFFFFu;
 #pragma unroll
                         for (int o = 0; o < RD_SEARCH_OUT; o++)
-                            m[o] &= rd_bits32_at(w, nwords, p0 + 32 * o + (long)k * cfg.S) ^ x;
+                            m[o] &= rd_bits32_at(w, nwords, (long)p0 + 32 * o + (long)k * cfg.S) ^ x;
                     }
                 }
+                // keep positions inside [p_lo, p_hi]: only the first and the last words of a stream
+                if (p0 < plo || p0 + 32 * RD_SEARCH_OUT - 1 > phi) {
 #pragma unroll
-                for (int o = 0; o < RD_SEARCH_OUT; o++) {  // keep positions inside [p_lo, p_hi]
-                    const long q0 = p0 + 32 * o;
-                    if (q0 < p_lo) m[o] &= (p_lo - q0 >= 32) ? 0u : (0xFFFFFFFFu << (p_lo - q0));
-                    if (q0 + 31 > p_hi) m[o] &= (p_hi < q0) ? 0u : (0xFFFFFFFFu >> (31 - (p_hi - q0)));
+                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                        const int q0 = p0 + 32 * o;
+                        if (q0 < plo) m[o] &= (plo - q0 >= 32) ? 0u : (0xFFFFFFFFu << (plo - q0));
+                        if (q0 + 31 > phi) m[o] &= (phi < q0) ? 0u : (0xFFFFFFFFu >> (31 - (phi - q0)));
+                    }
                 }
             }
 #pragma unroll
