@@ -325,6 +325,14 @@ __device__ __forceinline__ uint32_t rd_bits32_at(const uint32_t *w, long nwords,
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+// 32-bit variant (bit offsets inside one stream's array always fit)
+__device__ __forceinline__ uint32_t rd_bits32_at_i(const uint32_t *w, int nwords, int o) {
+    const int wi = o >> 5;  // arithmetic shift: floor
+    const uint32_t lo = (wi >= 0 && wi < nwords) ? w[wi] : 0u;
+    const uint32_t hi = (wi + 1 >= 0 && wi + 1 < nwords) ? w[wi + 1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(o & 31));
+}
+
 #define RD_SEARCH_OUT 4     // output words (32 positions each) per lane
 #define RD_MATCH_PEND 128   // staged matches per wave
 #define RD_SEARCH_WAVES 4    // waves per workgroup (16 was tried to cut the end-of-kernel atomics: no gain)
@@ -591,18 +599,21 @@ __device__ __forceinline__ void rd_rssi_f64(const View &v, long origin, const rd
 // PH0 = phase (index mod 4) of the first sample it reads - wave-uniform because every lane's
 // start differs by 8 samples - so the Fs/4 rotation and the dword/half selection are static.
 template <int PH0, int PER>
-__device__ __forceinline__ void rd_rssi_pass(const rd_stream_view &v, long n0, long j0, long q, long pe,
+__device__ __forceinline__ void rd_rssi_pass(const rd_stream_view &v, int n0, int j0, int q, int pe,
                                              float &noise, float &sig) {
+    // (32-bit indices: samples of one stream; 64-bit index arithmetic doubled this kernel's instructions)
+    const int vfrom = (int)v.valid_from, vn = (int)v.n;
     const float c[9] = {(float)RD_C0, (float)RD_C1, (float)RD_C2, (float)RD_C3, (float)RD_C4,
                         (float)RD_C3, (float)RD_C2, (float)RD_C1, (float)RD_C0};
     constexpr int ODD = PH0 & 1;
     constexpr int ND = (PER + 8 + ODD + 1) / 2;  // aligned dwords (two samples each) covering PER+8 samples
-    const long ne = n0 - ODD;
+    const int ne = n0 - ODD;
+    const uint32_t *src = (const uint32_t *)(v.base + 2 * (long)ne);
     uint32_t dw[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-        const long n = ne + 2 * d;
-        dw[d] = (n + 1 >= v.valid_from && n < v.n + 8) ? *(const uint32_t *)(v.base + 2 * n) : 0u;
+        const int n = ne + 2 * d;
+        dw[d] = (n + 1 >= vfrom && n < vn + 8) ? src[d] : 0u;
     }
     float yr[PER + 8], yi[PER + 8];
 #pragma unroll
@@ -612,7 +623,7 @@ __device__ __forceinline__ void rd_rssi_pass(const rd_stream_view &v, long n0, l
         const uint32_t h = dw[i >> 1] >> (16 * (i & 1));
         float a = ((float)(h & 0xFF) - 127.4f) * (1.0f / 127.6f);
         float b = ((float)((h >> 8) & 0xFF) - 127.4f) * (1.0f / 127.6f);
-        if (n0 + k < v.valid_from) { a = 0.0f; b = 0.0f; }
+        if (n0 + k < vfrom) { a = 0.0f; b = 0.0f; }
         const int ph = (PH0 + k) & 3;  // static
         yr[k] = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
         yi[k] = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
@@ -626,7 +637,7 @@ __device__ __forceinline__ void rd_rssi_pass(const rd_stream_view &v, long n0, l
             fi = __builtin_fmaf(c[m], yi[r + m], fi);
         }
         const float pw = fr * fr + fi * fi;
-        const long j = j0 + r;
+        const int j = j0 + r;
         if (j < pe) { if (j < q) noise += pw; else sig += pw; }
     }
 }
@@ -639,18 +650,19 @@ __device__ __forceinline__ float rd_wave_sum_f32(float v) {
 
 // uint8 input: the window means are evaluated in fp32 (|f|^2 to ~1e-6 relative; 10*log10 through
 // v_log_f32, ~3e-6 dB; the tolerance on RSSI/SNR is 1e-3 dB).
-__device__ __forceinline__ void rd_rssi_u8(const rd_stream_view &v, long origin, const rd_devcfg &cfg, long q,
+__device__ __forceinline__ void rd_rssi_u8(const rd_stream_view &v, long origin64, const rd_devcfg &cfg, long q64,
                                            int lane, double &rssi, double &snr) {
-    const long ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
-    const long pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
+    const int origin = (int)origin64, q = (int)q64;
+    const int ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
+    const int pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
     constexpr int PER = 8;  // outputs per lane per pass: 64 * 8 = 512 window positions per pass
     float noise = 0.0f, sig = 0.0f;
-    for (long jb = ns; jb < pe; jb += 64 * PER) {
-        const long j0 = jb + (long)PER * lane;
+    for (int jb = ns; jb < pe; jb += 64 * PER) {
+        const int j0 = jb + PER * lane;
         // outputs j0 .. j0+PER-1 are f[t], t = origin + j - 1, each using y[t-9 .. t-1]:
         // samples n0 .. n0 + PER + 7 with n0 = origin + j0 - 10
-        const long n0 = origin + j0 - 10;
-        const int ph0 = __builtin_amdgcn_readfirstlane((int)(n0 & 3));
+        const int n0 = origin + j0 - 10;
+        const int ph0 = __builtin_amdgcn_readfirstlane(n0 & 3);
         if (j0 < pe) {
             switch (ph0) {
                 case 0: rd_rssi_pass<0, PER>(v, n0, j0, q, pe, noise, sig); break;
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, c
         bool same_prev = true, same_next = true;
         for (int r = 0; r * 64 < cfg.K; r++) {
             const int k = 64 * r + lane;
-            const uint32_t tri = k < cfg.K ? rd_bits32_at(w, nwords, pos - 1 + (long)k * cfg.S) : 0u;
+            const uint32_t tri = k < cfg.K ? rd_bits32_at_i(w, (int)nwords, (int)pos - 1 + k * cfg.S) : 0u;
             const uint64_t mp = __ballot((tri & 1u) != 0), m = __ballot((tri & 2u) != 0), mn = __ballot((tri & 4u) != 0);
             same_prev &= mp == m;
             same_next &= mn == m;
