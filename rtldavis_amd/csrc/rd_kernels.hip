@@ -281,12 +281,15 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
                 // Dwords wholly before the first readable sample are not touched (no history there).
                 const uint8_t *p = v.base + 2 * (t0 - 10);
                 uint32_t dw[10];
+                // dword d holds samples t0-10+2d and +1.  Readable: its last sample is at or after
+                // valid_from (d >= floor(x / 2), x = valid_from - (t0-10)) and its first sample lies
+                // before the input's padded end (d < ceil(z / 2), z = n_samples + 8 - (t0-10)).
+                // Two 64-bit subtractions, then 32-bit compares against constants.
+                const long x = v.valid_from - (t0 - 10), z = (long)lay.n_samples + 8 - (t0 - 10);
+                const int d_lo = x <= 0 ? 0 : x >= 20 ? 10 : (int)(x / 2);
+                const int d_hi = z <= 0 ? 0 : z >= 20 ? 10 : (int)((z + 1) / 2);
 #pragma unroll
-                for (int d = 0; d < 10; d++) {
-                    const long n_hi = t0 - 10 + 2 * d + 1;  // last sample in this dword
-                    dw[d] = (n_hi >= v.valid_from && t0 - 10 + 2 * d < (long)lay.n_samples + 8)
-                                ? *(const uint32_t *)(p + 4 * d) : 0u;
-                }
+                for (int d = 0; d < 10; d++) dw[d] = (d >= d_lo && d < d_hi) ? *(const uint32_t *)(p + 4 * d) : 0u;
                 ((uint8_t *)lay.bits)[(size_t)widx * 4 + g] = (uint8_t)rd_exact_group_dw(dw, t0, count, v.valid_from);
             }
         }

@@ -410,12 +410,15 @@ RD_HD uint32_t rd_exact_bit_f64(rd_dd2 n, rd_dd2 np) {
 // `first_valid`: samples with index < first_valid (zero history) read as y = 0.
 RD_HD uint32_t rd_exact_group_dw(const uint32_t *dw, long t0, int count, long first_valid) {
     rd_dd2 y[17];  // rotated integer samples t0-10 .. t0+6 as doubles (t0 % 4 == 0: static phases)
+    // window samples i < zh lie before the first readable sample (one 64-bit subtraction, then
+    // 32-bit compares against constants)
+    const long zh64 = first_valid - (t0 - 10);
+    const int zh = zh64 <= 0 ? 0 : zh64 >= 17 ? 17 : (int)zh64;
 #pragma unroll
     for (int i = 0; i < 17; i++) {
-        const long n = t0 - 10 + i;
         const uint32_t d = dw[i >> 1] >> (16 * (i & 1));
         double a = (double)(5 * (int)(d & 0xFF) - 637), b = (double)(5 * (int)((d >> 8) & 0xFF) - 637);
-        if (n < first_valid) { a = 0.0; b = 0.0; }  // zero history: y = 0 (5k-637 is never 0 otherwise)
+        if (i < zh) { a = 0.0; b = 0.0; }  // zero history: y = 0 (5k-637 is never 0 otherwise)
         const int ph = (i + 2) & 3;  // (t0 - 10 + i) mod 4
         y[i].x = ph == 0 ? a : ph == 1 ? -b : ph == 2 ? -a : b;
         y[i].y = ph == 0 ? b : ph == 1 ? a : ph == 2 ? -b : -a;
