@@ -158,9 +158,10 @@ int rd_batch_copy_discriminated(rd_batch *b, int stream, size_t t0, double *out,
  * after a run, rd_batch_parsed returns the CRC-valid messages sorted like rd_batch_results. */
 int rd_batch_set_parse(rd_batch *b, int enabled);
 int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n);
-/* HIP-event timing on the run's stream.  enabled = 1: the demod kernel and the whole run (three
- * events per run; each event between two kernels costs ~6 us of GPU idle time); 2: every stage
- * (five events); 0: off.  get_timing synchronises, returns the mean over the runs recorded so
+/* HIP-event timing on the run's stream.  enabled = 1: the demod kernel and the whole run (its
+ * start/stop events and the end-of-run event are attached to the kernel dispatches themselves, so
+ * they cost no idle time); 2: every stage (two more events recorded between kernels, ~6 us of GPU
+ * idle time each); 0: off.  get_timing synchronises, returns the mean over the runs recorded so
  * far and starts a new window (stages not timed read 0). */
 int rd_batch_set_timing(rd_batch *b, int enabled);
 int rd_batch_get_timing(rd_batch *b, rd_timing *out);

@@ -375,8 +375,11 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
                      b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
     if (b->timing && b->timing_detail) hipEventRecord(b->ev[3], st);
+    // the run's last kernel carries the end-of-run event itself when nothing follows it
+    hipEvent_t last = b->timing ? b->ev[4] : b->kdone;
+    const bool last_on_slice = !b->parse;
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
-                    b->d_recs, nullptr, batch_cnt(b), st);
+                    b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr);
     if (b->parse) {
         if (!b->d_parsed) hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed));
         if (b->d_parsed) rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
@@ -386,8 +389,7 @@ static void batch_search_slice(rd_batch *b, hipStream_t st) {
     // The copies run on their own stream so that another batch's kernels queued on `st` need
     // not wait for them.  Every event recorded between two kernels idles the GPU for a few
     // microseconds, so a timed run's end-of-run event doubles as the copy stream's trigger.
-    hipEvent_t last = b->timing ? b->ev[4] : b->kdone;
-    hipEventRecord(last, st);
+    if (!last_on_slice) hipEventRecord(last, st);
     hipStreamWaitEvent(b->copy_stream, last, 0);
     hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
     const uint32_t spec = std::min(b->match_cap, b->spec_recs);
@@ -420,9 +422,14 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         b->ev = &b->evs[5 * b->ev_runs];
         b->ev_runs++;
     }
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
-    if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st);
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
+    if (b->timing && b->fast_ok) {
+        // the demod kernel's dispatch carries its own start / stop events (no marker packets)
+        rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1]);
+    } else {
+        if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
+        if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st);
+        if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
+    }
     rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
     batch_search_slice(b, st);

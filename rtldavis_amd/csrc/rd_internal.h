@@ -40,7 +40,9 @@ struct rd_match {
 };
 
 // --- launches (all asynchronous on `st`) ---
-void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st);
+// ev_start / ev_stop (optional): events that receive the kernel's own begin / end timestamps.
+void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_SLOTS counters to clear for the handle's next run.
@@ -61,7 +63,8 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 // is given; with recs_host the records need no device-to-host copy.
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st);
+                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st,
+                     hipEvent_t ev_stop = nullptr);
 // Parser.parse front half (protocol.py:290-311) over the records of a batch run (layout as
 // above): CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
 void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,

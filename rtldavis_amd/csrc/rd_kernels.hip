@@ -18,6 +18,8 @@
 // 9-tap window lives in registers and one lane emits one packed 32-bit word.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "rd_internal.h"
 #include "rd_math.h"
 
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
     if (npend) rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
 }
 
-void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st) {
+void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                     hipEvent_t ev_start, hipEvent_t ev_stop) {
     const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
     const uint64_t total = (uint64_t)lay.n_streams * tps;
@@ -219,8 +222,17 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
         const char *n = getenv("RD_K1_NPK");  // packed FIR steps per output, for tuning sweeps
         if (n) npk = atoi(n);
     }
-#define RD_LAUNCH_K1(D, N) \
-    hipLaunchKernelGGL((k_demod_bits<D, N>), dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps, fix_list, fix_cap, counters)
+    // With events given, the dispatch itself carries them (hipExtLaunchKernelGGL): its begin / end
+    // timestamps, without the marker packets of hipEventRecord that idle the GPU for ~6 us each.
+#define RD_LAUNCH_K1(D, N)                                                                                          \
+    do {                                                                                                            \
+        if (ev_start || ev_stop)                                                                                    \
+            hipExtLaunchKernelGGL((k_demod_bits<D, N>), dim3((unsigned)wgs), dim3(RD_WG), 0, st, ev_start, ev_stop, \
+                                  0, lay, tps, rps, fix_list, fix_cap, counters);                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_demod_bits<D, N>), dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps,        \
+                               fix_list, fix_cap, counters);                                                        \
+    } while (0)
     if (dbg == 1) RD_LAUNCH_K1(1, RD_NPK_DEFAULT);
     else if (dbg == 2) RD_LAUNCH_K1(2, RD_NPK_DEFAULT);
     else if (npk == 0) RD_LAUNCH_K1(0, 0);
@@ -825,12 +837,17 @@ static uint32_t rd_slice_grid(uint32_t match_cap) {
 
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st) {
+                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop) {
     rd_u8_src src;
     src.lay = lay;
-    hipLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
-                       bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap, batch_mode, n_calls, call, recs,
-                       recs_host, counters);
+    if (ev_stop)  // the dispatch records the event itself (no marker packet behind the kernel)
+        hipExtLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, nullptr,
+                              ev_stop, 0, src, bits, bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap,
+                              batch_mode, n_calls, call, recs, recs_host, counters);
+    else
+        hipLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
+                           bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap, batch_mode, n_calls, call, recs,
+                           recs_host, counters);
 }
 
 // ------------------------------------------------------------------------------------------
