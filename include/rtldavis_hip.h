@@ -224,6 +224,21 @@ int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_stream_strid
 /* Same, into a host array uint8 [n_channels][n_out][2] (synchronous). */
 int rd_chan_run_host(rd_chan *h, size_t n_out, uint8_t *out_host, size_t nbytes);
 
+/* ---------------------------------------------------------------------------------------------
+ * Test hooks of the fused demod kernel (rtldavis_amd/csrc/rd_demod_mfma.hip).  Not part of the
+ * drop-in surface: tests/test_mfma_model.py and tests/test_gpu_mfma.py use them to check the tap
+ * matrix and the raw matrix-pipe outputs against an integer model.
+ * ------------------------------------------------------------------------------------------- */
+/* The constant A operand: uint16 [2 digits][3 k-steps][64 lanes][8 elements] f16 bit patterns. */
+void rd_debug_mfma_taps(uint16_t *out);
+/* Run k_demod_mfma alone on host data: g_out float [n_streams * tiles][2048][2] (kernel units),
+ * bits_out the packed signs BEFORE the exact fix-up (words per stream = ceil(n_samples / 32)),
+ * fix_out / n_fix the fix-up list it produced ((word index << 4) | group mask).  hist_mode: every
+ * stream is preceded by hist_bytes of history (stride = hist_bytes + 2 n_samples, multiples of 16). */
+int rd_debug_demod_mfma(const uint8_t *iq_host, int n_streams, uint32_t n_samples, int hist_mode,
+                        uint32_t hist_bytes, float *g_out, uint32_t *bits_out, uint32_t *fix_out,
+                        uint32_t fix_cap, uint32_t *n_fix);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,10 +39,17 @@ struct rd_match {
     int32_t pos;  // bit-array coordinate of the first preamble sample
 };
 
+// lazy, fork-aware HIP initialisation (rd_api.hip); RD_OK or RD_ERR_DEVICE
+int rd_ensure_device_public(void);
+
 // --- launches (all asynchronous on `st`) ---
 // ev_start / ev_stop (optional): events that receive the kernel's own begin / end timestamps.
 void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// The same stage with the FIR on the matrix pipe (rd_demod_mfma.hip); rd_launch_demod dispatches to it
+// unless RD_K1_IMPL=valu.  dbg_g (test hook): when given, the kernel also dumps g[tile][2048][2].
+void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_SLOTS counters to clear for the handle's next run.

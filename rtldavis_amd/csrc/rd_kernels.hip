@@ -201,6 +201,16 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
 
 void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                      hipEvent_t ev_start, hipEvent_t ev_stop) {
+    // RD_K1_IMPL=valu keeps the round-1 kernel (FIR on the VALU) for A/B runs; default: matrix pipe
+    static int impl = -1;
+    if (impl < 0) {
+        const char *e = getenv("RD_K1_IMPL");
+        impl = (e && e[0] == 'v') ? 0 : 1;
+    }
+    if (impl == 1) {
+        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop);
+        return;
+    }
     const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
     const uint64_t total = (uint64_t)lay.n_streams * tps;

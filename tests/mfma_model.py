@@ -1,0 +1,108 @@
+"""NumPy model of k_demod_mfma's data flow (rtldavis_amd/csrc/rd_demod_mfma.hip, rd_mfma.h).
+TEST INFRASTRUCTURE ONLY.
+
+It follows the kernel lane by lane: which window bytes a lane holds, the element order of the B
+fragment, the documented lane maps of v_mfma_f32_32x32x16_f16 (A[row = lane & 31][k = 8 (lane >> 5) + j],
+B[k][col = lane & 31], D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31]) and the tap
+matrix the library exports (rd_debug_mfma_taps).  Everything is an integer, so the model is exact;
+tests compare it with a direct evaluation of g[t] = sum_m T_m j^m U[t-9+m] and with the oracle.
+"""
+from __future__ import annotations
+
+from fractions import Fraction
+
+import numpy as np
+
+TILE = 2048
+SCALE = 17683709.98098367
+T = (312688, 851848, 2164923, 3490915, 4042962)
+C12 = (17682261285, 48171339939, 122424706672, 197408519126, 228626345955)  # fir9 taps * 1e12 (dsp.py:56-69)
+ELEM = (0, 2, 1, 3, 4, 6, 5, 7)  # element j of a B fragment = byte ELEM[j] of the lane's 8 window bytes
+E0 = 0.0107  # RD_MF_E0
+
+
+def taps_from_lib() -> np.ndarray:
+    """[digit][k-step][lane][element] as float64 (decoded f16)."""
+    from rtldavis_amd import _lib
+    raw = np.zeros(2 * 3 * 64 * 8, dtype=np.uint16)
+    _lib.lib().rd_debug_mfma_taps(raw.ctypes.data)
+    return raw.view(np.float16).astype(np.float64).reshape(2, 3, 64, 8)
+
+
+def tap_error_sum() -> Fraction:
+    """sum over the nine taps of |T_m - S c_m| in exact rational arithmetic."""
+    s = Fraction(SCALE)
+    eps = [abs(Fraction(t) - s * Fraction(c, 10 ** 12)) for t, c in zip(T, C12)]
+    return 2 * sum(eps[:4]) + eps[4]
+
+
+def centred(raw: np.ndarray) -> np.ndarray:
+    """U = 5 k - 637 per byte (x = U / 638, dsp.py:26)."""
+    return 5 * raw.astype(np.int64) - 637
+
+
+def g_direct(raw: np.ndarray, hist: np.ndarray | None = None) -> np.ndarray:
+    """g[t] = sum_m T_m j^m U[t-9+m] for t = 0..n (n+1 values), complex with integer parts.
+    Samples before the stream are `hist` bytes (interleaved, oldest first) or - with no history -
+    the zero state y = 0 of dsp.py:131."""
+    u = centred(raw)
+    z = (u[0::2] + 1j * u[1::2])
+    if hist is None:
+        pre = np.zeros(9, dtype=np.complex128)
+    else:
+        uh = centred(hist)
+        pre = (uh[0::2] + 1j * uh[1::2])[-9:]
+    zp = np.concatenate([pre, z])
+    n = z.size
+    taps = [T[m if m <= 4 else 8 - m] * (1j ** m) for m in range(9)]
+    g = np.zeros(n + 1, dtype=np.complex128)
+    for m in range(9):
+        g += taps[m] * zp[m: m + n + 1] if m + n + 1 <= zp.size else 0
+    return g
+
+
+def model_tile(win: np.ndarray, taps: np.ndarray) -> np.ndarray:
+    """One tile through the kernel's lane maps.  `win` = the 16 bytes before the tile followed by the
+    tile's 4096 bytes.  Returns g (complex, integer parts) for outputs t = 1 .. 2048 of the tile
+    (index t - 1), i.e. lane (n, h), block b, register pair r -> t = 64 n + 16 b + 8 h + 1 + r."""
+    assert win.size == 16 + 2 * TILE
+    u = centred(win).astype(np.float64)
+    out = np.zeros(TILE, dtype=np.complex128)
+    lanes = np.arange(64)
+    n, h = lanes & 31, lanes >> 5
+    for b in range(4):
+        acc = np.zeros((2, 32, 32))  # [digit][row][col]
+        for d in range(3):
+            # B[k = 8 h + j][col n] = window byte 128 n + 16 (2b + d) + 8 h + ELEM[j] of the column window,
+            # whose origin is 16 bytes before the column: win index = that (win already starts 16 bytes early)
+            bmat = np.zeros((16, 32))
+            for lane in lanes:
+                for j in range(8):
+                    bmat[8 * h[lane] + j, n[lane]] = u[128 * n[lane] + 16 * (2 * b + d) + 8 * h[lane] + ELEM[j]]
+            for dig in range(2):
+                amat = np.zeros((32, 16))
+                for lane in lanes:
+                    amat[lane & 31, 8 * (lane >> 5): 8 * (lane >> 5) + 8] = taps[dig, d, lane]
+                acc[dig] += amat @ bmat
+        full = 2048.0 * acc[0] + acc[1]
+        for lane in lanes:
+            for reg in range(16):
+                row = (reg & 3) + 8 * (reg >> 2) + 4 * h[lane]
+                r, comp = reg >> 1, reg & 1
+                t = 64 * n[lane] + 16 * b + 8 * h[lane] + 1 + r
+                v = full[row, n[lane]]
+                out[t - 1] += v * (1j if comp else 1)
+    return out
+
+
+def bits_from_g(g: np.ndarray) -> np.ndarray:
+    """bit[t] = signbit(-(Re g[t-1] conj g[t])) for t = 0..n-1 given g[-1..n-1] (g[0] = g at t = -1)."""
+    p = (g[:-1] * np.conj(g[1:])).real
+    return (p > 0).astype(np.uint8)
+
+
+def threshold(F: np.ndarray) -> np.ndarray:
+    """rd_mf_threshold in float32 arithmetic."""
+    F = F.astype(np.float32)
+    return ((F * (np.float32(4.0) * np.float32(E0) + np.float32(4.76837158e-7) * F) + np.float32(3.0e-4))
+            * np.float32(1.000001))

@@ -1,0 +1,105 @@
+"""CPU checks of the matrix-pipe FIR formulation (rd_mfma.h): the exported tap matrix pushed through
+the documented MFMA lane maps reproduces g[t] = sum_m T_m j^m U[t-9+m] exactly, the arithmetic stays
+inside f32's exact-integer range, the error constant is what exact rational arithmetic gives, and the
+guard band built on it covers every sign the oracle disagrees with."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import mfma_model as M  # noqa: E402
+from oracle import dsp_oracle as O  # noqa: E402
+from rtldavis_amd.synth import synth_stream  # noqa: E402
+
+
+def test_tap_scale_and_error_constant():
+    # T_m = round(S c_m); the summed quantisation error is what rd_mfma.h states
+    for t, c in zip(M.T, M.C12):
+        assert t == round(M.SCALE * c / 1e12)
+    eps = M.tap_error_sum()
+    assert abs(float(eps) - 0.0677192) < 1e-6
+    e0 = float(eps) * 638 / 4096
+    assert e0 < M.E0 < 1.02 * e0  # RD_MF_E0 bounds it with < 2 % slack
+    # in byte units of f: 70 times below the fp32 VALU path's 3.3e-5
+    assert M.E0 / (5 * M.SCALE / 4096) < 5.0e-7
+
+
+def test_digits_are_f16_exact_and_sums_stay_below_2_24():
+    taps = M.taps_from_lib()
+    assert np.all(taps == np.rint(taps)) and np.abs(taps).max() <= 2048
+    # per output row: sum |digit| * max|U| bounds every partial sum of the f32 accumulation
+    for dig in range(2):
+        rows = np.zeros(32)
+        for d in range(3):
+            for lane in range(64):
+                rows[lane & 31] += np.abs(taps[dig, d, lane]).sum()
+        assert rows.max() * 638 < 2 ** 24, (dig, rows.max() * 638)
+    # hi * 2048 + lo reproduces the signed integer taps
+    full = 2048 * taps[0] + taps[1]
+    assert set(np.unique(np.abs(full)).astype(np.int64)) == {0, *M.T}
+
+
+def test_lane_maps_reproduce_the_direct_filter():
+    rng = np.random.default_rng(5)
+    taps = M.taps_from_lib()
+    for trial in range(3):
+        raw = rng.integers(0, 256, size=16 + 2 * M.TILE, dtype=np.uint8)
+        if trial == 1:
+            raw[:] = rng.choice(np.array([0, 255], dtype=np.uint8), size=raw.size)  # extreme magnitudes
+        got = M.model_tile(raw, taps)
+        # history for the direct form: the 16-byte halo (8 samples) behind one filler sample; g[1], the
+        # first output the kernel computes, starts exactly at the halo (samples -8 .. 0)
+        want = M.g_direct(raw[16:], hist=np.concatenate([np.full(2, 127, np.uint8), raw[:16]]))
+        assert np.array_equal(got, want[1: M.TILE + 1]), trial
+
+
+def test_rotation_free_numerator_matches_the_oracle():
+    raw = synth_stream(3, n_samples=4 * 8192)
+    _, _, bits = O.demod_stream_oneshot(raw)
+    g = M.g_direct(raw)  # g[t], t = 0..n with zero history
+    gm1 = np.concatenate([[0], g[:-1]])  # g[t-1] for t = 0..n
+    p = (gm1 * np.conj(g)).real[: bits.size]
+    mine = (p > 0).astype(np.uint8)
+    # exact integers: the only disagreements possible are exact zeros (zero history start)
+    bad = np.nonzero(mine != bits)[0]
+    assert bad.size == 0 or bad.max() < 10, bad[:10]
+
+
+def test_guard_band_covers_every_mismatch():
+    """Signs decided from float32(G) with the kernel's threshold: every sample whose fast sign differs
+    from the oracle's lies in a flagged group - on noise, on a weak signal and on +-1 LSB data."""
+    rng = np.random.default_rng(11)
+    cases = [synth_stream(7, n_samples=4 * 8192), synth_stream(8, n_samples=4 * 8192, amplitude=0.02, noise=0.01)]
+    tiny = (127 + rng.integers(0, 2, size=2 * 4 * 8192)).astype(np.uint8)
+    cases.append(tiny)
+    total_flagged = 0
+    for raw in cases:
+        _, _, bits = O.demod_stream_oneshot(raw)
+        g = M.g_direct(raw) / 4096.0  # kernel units
+        gf_re = g.real.astype(np.float32)
+        gf_im = g.imag.astype(np.float32)
+        n = bits.size
+        a, b = gf_re[:n], gf_im[:n]          # g[t-1] for t = 1..n  (index t-1)
+        c, d = gf_re[1: n + 1], gf_im[1: n + 1]
+        num = -(a.astype(np.float64) * c + b.astype(np.float64) * d)  # close enough to the fp32 fma pair
+        num32 = (np.float32(-1) * a * c - (b * d)).astype(np.float32)
+        fast = np.signbit(num32).astype(np.uint8)
+        # groups of 8 samples t = 8k+1 .. (model of "min |num| over the group" against thr(F), F per 32 samples)
+        t = np.arange(1, n)
+        F = np.maximum(np.maximum(np.abs(a), np.abs(b)), np.maximum(np.abs(c), np.abs(d)))[: n - 1]
+        grp = (t // 8)
+        run = (t // 32)
+        Frun = np.zeros(run.max() + 1, dtype=np.float32)
+        np.maximum.at(Frun, run, F)
+        thr = M.threshold(Frun)[run]
+        flagged_sample = np.abs(num32[: n - 1]) <= thr
+        flagged_group = np.zeros(grp.max() + 1, dtype=bool)
+        np.logical_or.at(flagged_group, grp, flagged_sample)
+        mism = fast[: n - 1] != bits[1:n]
+        assert not np.any(mism & ~flagged_group[grp]), "a wrong sign outside the guard band"
+        total_flagged += int(flagged_group.sum())
+        del num
+    assert total_flagged > 0  # the +-1 LSB case does hit exact zeros
