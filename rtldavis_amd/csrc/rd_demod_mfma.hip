@@ -36,17 +36,17 @@
 // 32 lanes that all read the same half of their 16-byte chunks.
 #define RD_MF_GROUP_BYTES 1152
 #define RD_MF_IMG_BYTES (16 + 4 * RD_MF_GROUP_BYTES)   // 4624
-#define RD_MF_IMG_PAD 4640
-// predecessor exchange: 4 step buffers of 64 x 16 B, then two carry slots (tile parity)
-#define RD_MF_XB_BYTES (1024 + 4 * 1024 + 32)  // 1 KiB in front keeps every base address non-negative
+#define RD_MF_IMG_PAD 4624
+// predecessor exchange: three buffers of 64 x 16 B, then two carry slots (tile parity)
+#define RD_MF_XB_BYTES (3 * 1024 + 32)
 #define RD_MF_PEND 64
-#define RD_MF_LDS_WAVE (RD_MF_IMG_PAD + RD_MF_XB_BYTES + RD_MF_PEND * 4)
 
 typedef _Float16 rd_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
 typedef float rd_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t rd_u4v __attribute__((ext_vector_type(4)));
 typedef float rd_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t rd_u2v __attribute__((ext_vector_type(2)));
 
 __device__ const rd_mf_taps g_mf_taps = rd_mf_make_taps();
 static const rd_mf_taps h_mf_taps = rd_mf_make_taps();
@@ -63,7 +63,7 @@ __device__ __forceinline__ uint32_t rd_mf_center(uint32_t two) {
 }
 
 // the lane's 8 window bytes of one k-step -> B fragment (element order RD_MF_ELEM)
-__device__ __forceinline__ rd_h8 rd_mf_frag(uint2 d) {
+__device__ __forceinline__ rd_h8 rd_mf_frag(rd_u2v d) {
     rd_u4v v;
     // bytes 1 and 3 of a dword into the low bytes of the two halves: one v_perm_b32 (selector 0x0c = 0x00)
     v.x = rd_mf_center(d.x & 0x00FF00FFu);
@@ -73,9 +73,20 @@ __device__ __forceinline__ rd_h8 rd_mf_frag(uint2 d) {
     return __builtin_bit_cast(rd_h8, v);
 }
 
-// -(ar cr + ai ci): numerator of py:89 for n = (ar, ai), n+ = (cr, ci) in the g frame
-__device__ __forceinline__ float rd_mf_num(float ar, float ai, float cr, float ci) {
-    return __builtin_fmaf(-ar, cr, -(ai * ci));
+// -(ar cr + ai ci): numerator of py:89 for n = (ar, ai), n+ = (cr, ci) in the g frame; also
+// r = |num| - 2^-21 |ai ci|, the numerator less the part of its error bound that scales with the
+// products (rd_mfma.h): one more fma, with free abs / neg modifiers.
+__device__ __forceinline__ float rd_mf_num(float ar, float ai, float cr, float ci, float &r) {
+    const float t1 = ai * ci;
+    const float num = __builtin_fmaf(-ar, cr, -t1);
+    r = __builtin_fmaf(-4.76837158e-7f, __builtin_fabsf(t1), __builtin_fabsf(num));
+    return num;
+}
+// min(m, a, b) without abs (r may be negative: then the group is inside the band anyway)
+__device__ __forceinline__ float rd_min3(float m, float a, float b) {
+    float o;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(m), "v"(a), "v"(b));
+    return o;
 }
 
 
@@ -96,29 +107,66 @@ __device__ __forceinline__ void rd_lds_wait(rd_f4v &r) { asm volatile("s_waitcnt
 __device__ __forceinline__ void rd_lds_write4(uint32_t addr, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
 }
+__device__ __forceinline__ rd_u4v rd_lds_read16u(uint32_t addr) {
+    rd_u4v r;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t rd_lds_read4(uint32_t addr) {
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+    return r;
+}
 __device__ __forceinline__ uint32_t rd_lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
 struct rd_mf_state {
-    float F;          // max |component| seen
     uint32_t W;       // sign bits, first sample at the top (reversed at the end)
-    float nmin[4];    // min |numerator| of each block's group
+    uint32_t fbytes;  // byte b != 0: block b's group is inside the guard band
     float g0r, g0i;   // block 0's first output: its two boundary numerators come last
 };
 
+// Guard band in two steps (bound: rd_mfma.h).  Per sample r = |num| - 2^-21 |b d| takes care of the part of
+// the error that scales with the products; what is left, 4 E0 F + const, needs F = the largest |component|
+// involved.  The common path compares a group's min r with that term at F = the largest |g| ANY input can
+// produce (RD_MF_C0_MAX, 2.6e-4 byte units squared: ~1e-5 of the samples of a noise input are below it);
+// only when some lane of the wave fails that test - a wave-uniform branch - is F taken from the values at
+// hand (v_max3 over the block) and the test repeated with it.
+__device__ __forceinline__ bool rd_mf_any(bool c) { return __ballot(c) != 0; }
+
 // One 16-output block of the tile: 6 MFMAs, the digit combine, then this lane's group of 8 signs.
-// xw: LDS address this lane's (g6, g7) go to (+ 1024 B); xr: where its predecessors' are (+ 1024 B).
-template <int B, int DBG>
+// xw + WOFF: LDS address this lane's (g6, g7) go to; xr: where its predecessors' are.
+template <int B, int DBG, int WOFF>
 __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_h8 (&bf)[9],
                                             uint32_t xw, uint32_t xr, rd_mf_state &st, float *dg, int dleft) {
     const rd_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    rd_f16v ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[0], bf[2 * B], zero, 0, 0, 0);
-    rd_f16v al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], bf[2 * B], zero, 0, 0, 0);
-    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], bf[2 * B + 1], ah, 0, 0, 0);
-    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], bf[2 * B + 1], al, 0, 0, 0);
-    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2 * B + 2], ah, 0, 0, 0);
-    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2 * B + 2], al, 0, 0, 0);
+    // The six MFMAs go out as one burst with no vector instruction between them: a wave then sits in the
+    // matrix pipe's queue for ~192 cycles while the other waves of the SIMD issue their VALU work, instead
+    // of every wave stalling at an MFMA every few instructions (in-order issue: measured 1450 -> ... cycles/tile)
+    __builtin_amdgcn_sched_barrier(0);
+    rd_f16v ah, al;
+    if (DBG == 4) {  // ablation: no matrix pipe, the vector work on stand-in values
+        const rd_u4v q0 = __builtin_bit_cast(rd_u4v, bf[2 * B]), q1 = __builtin_bit_cast(rd_u4v, bf[2 * B + 1]),
+                     q2 = __builtin_bit_cast(rd_u4v, bf[2 * B + 2]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            ah[i] = __builtin_bit_cast(float, (i & 8 ? q1 : q0)[i & 3] | 0x3f000000u) + (float)i;
+            al[i] = __builtin_bit_cast(float, (i & 8 ? q2 : q1)[i & 3] | 0x3f000000u);
+        }
+    } else {
+        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[0], bf[2 * B], zero, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], bf[2 * B], zero, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], bf[2 * B + 1], ah, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], bf[2 * B + 1], al, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2 * B + 2], ah, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2 * B + 2], al, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG == 5) {  // ablation: the matrix pipe with next to no vector work behind it
+        st.W ^= __builtin_bit_cast(uint32_t, ah[0] + al[15]);
+        return;
+    }
     float g[16];  // g[2r], g[2r+1] = re, im of output r of this lane's group
 #pragma unroll
     for (int i = 0; i < 16; i++) g[i] = __builtin_fmaf(ah[i], 2048.0f, al[i]);
@@ -129,19 +177,18 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     }
     {
         const rd_f4v x = {g[12], g[13], g[14], g[15]};
-        rd_lds_write16<1024 * B>(xw, x);
+        rd_lds_write16<WOFF>(xw, x);
     }
     rd_f4v p = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (B > 0) p = rd_lds_read16<1024 * B>(xr);  // g[base-1], g[base]: in flight under the group's own work
-#pragma unroll
-    for (int r = 0; r < 8; r++) st.F = rd_max3abs(st.F, g[2 * r], g[2 * r + 1]);
+    if (B > 0) p = rd_lds_read16<0>(xr);  // g[base-1], g[base]: in flight under the group's own work
     float nm = 3.0e38f;
     uint32_t w6 = 0;
 #pragma unroll
     for (int q = 2; q < 8; q += 2) {
-        const float na = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1]);
-        const float nb = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1]);
-        nm = rd_min3abs(nm, na, nb);
+        float ra, rb;
+        const float na = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1], ra);
+        const float nb = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1], rb);
+        nm = rd_min3(nm, ra, rb);
         w6 = rd_shift_in_sign(w6, na);
         w6 = rd_shift_in_sign(w6, nb);
     }
@@ -150,16 +197,26 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
         st.W = w6;
     } else {
         rd_lds_wait(p);
-        st.F = rd_max3abs(st.F, p.x, p.y);
-        st.F = rd_max3abs(st.F, p.z, p.w);
-        const float n0 = rd_mf_num(p.x, p.y, p.z, p.w);
-        const float n1 = rd_mf_num(p.z, p.w, g[0], g[1]);
-        nm = rd_min3abs(nm, n0, n1);
+        float r0, r1;
+        const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, r0);
+        const float n1 = rd_mf_num(p.z, p.w, g[0], g[1], r1);
+        nm = rd_min3(nm, r0, r1);
         uint32_t w2 = rd_shift_in_sign(0u, n0);
         w2 = rd_shift_in_sign(w2, n1);
         st.W = (st.W << 8) | (w2 << 6) | w6;
     }
-    st.nmin[B] = nm;
+    if (DBG == 0 || DBG == 3) {
+        if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {  // rare; NaN counts as inside
+            float F = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 8; r++) F = rd_max3abs(F, g[2 * r], g[2 * r + 1]);
+            if (B > 0) {
+                F = rd_max3abs(F, p.x, p.y);
+                F = rd_max3abs(F, p.z, p.w);
+            }
+            if (!(nm > rd_mf_c0(F))) st.fbytes |= 1u << (8 * B);
+        }
+    }
 }
 
 __device__ __forceinline__ void rd_mf_issue(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *img, int lane) {
@@ -190,21 +247,78 @@ __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count
         if (base + i < fix_cap) fix_list[base + i] = pend[i];
 }
 
+// Store the staged words: four tiles as one 16-byte store per lane, fewer tile by tile.
+__device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t nst, uint32_t *base, int lane,
+                                                   uint32_t stflags) {
+    if (nst == 4) {
+        const rd_u4v v = rd_lds_read16u(stage_addr + 16 * lane);
+        if (stflags & 1) __builtin_nontemporal_store(v, (rd_u4v *)(base + 4 * lane));
+        else *(rd_u4v *)(base + 4 * lane) = v;
+    } else {
+        for (uint32_t q = 0; q < nst; q++) base[64 * q + lane] = rd_lds_read4(stage_addr + 256 * q + 4 * lane);
+    }
+}
+
+// position of a wave in its sequence of tiles: chunks of `chunk` consecutive tiles, nwaves chunks apart
+struct rd_mf_pos {
+    uint32_t tile, s, ti, inchunk;
+};
+__device__ __forceinline__ rd_mf_pos rd_mf_next(rd_mf_pos p, uint32_t chunk, uint32_t tps, uint32_t jump, uint32_t jq,
+                                                uint32_t jr) {
+    rd_mf_pos q;
+    if (p.inchunk + 1 < chunk) {
+        q.tile = p.tile + 1; q.inchunk = p.inchunk + 1;
+        q.s = p.s; q.ti = p.ti + 1;
+        if (q.ti >= tps) { q.ti = 0; q.s++; }
+    } else {
+        q.tile = p.tile + jump; q.inchunk = 0;
+        q.s = p.s + jq; q.ti = p.ti + jr;
+        if (q.ti >= tps) { q.ti -= tps; q.s++; }
+    }
+    return q;
+}
+
+// The nine 8-byte window pieces of a lane.  Inline asm for the same reason as the exchange buffer: a
+// compiler-visible LDS read would wait for vmcnt(0), i.e. for the tiles that are being prefetched into
+// the OTHER image buffer.
+__device__ __forceinline__ void rd_mf_read_window(uint32_t a_prv, uint32_t a_own, rd_u2v (&D)[9]) {
+    asm volatile("ds_read_b64 %0, %9\n\t"
+                 "ds_read_b64 %1, %10\n\t"
+                 "ds_read_b64 %2, %10 offset:128\n\t"
+                 "ds_read_b64 %3, %10 offset:256\n\t"
+                 "ds_read_b64 %4, %10 offset:384\n\t"
+                 "ds_read_b64 %5, %10 offset:512\n\t"
+                 "ds_read_b64 %6, %10 offset:640\n\t"
+                 "ds_read_b64 %7, %10 offset:768\n\t"
+                 "ds_read_b64 %8, %10 offset:896\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(D[0]), "=&v"(D[1]), "=&v"(D[2]), "=&v"(D[3]), "=&v"(D[4]), "=&v"(D[5]), "=&v"(D[6]),
+                   "=&v"(D[7]), "=&v"(D[8])
+                 : "v"(a_prv), "v"(a_own)
+                 : "memory");
+}
+
 // DBG: 0 product; 1 no global loads; 2 loads + LDS reads only; 3 also dumps g (dbg_g[tile][2048][2],
-// sample order) - 1 and 2 are timing ablations with garbage results.
-template <int DBG>
+// sample order); 4 = 1 without the MFMAs; 5 = 1 with the MFMAs and almost no vector work - 1, 2, 4, 5 are
+// timing ablations with garbage results.
+template <int DBG, int NBUF>
 __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
                                                          uint32_t chunk, uint32_t *fix_list, uint32_t fix_cap,
-                                                         uint32_t *counters, float *dbg_g) {
-    // three separate arrays: the compiler then knows that the exchange buffer and the pending list do not
-    // alias the image the LDS-DMA writes, and does not drain vmcnt (the NEXT tile's loads) before them
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[RD_MF_WAVES][RD_MF_IMG_PAD];
+                                                         uint32_t *counters, float *dbg_g, uint32_t stflags) {
+    // NBUF = 2: two image buffers per wave, while tile i is computed tiles i+1 and i+2 are in flight
+    // (3 workgroups per CU); NBUF = 1: one buffer, tile i+1 in flight (4 workgroups per CU).
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[RD_MF_WAVES][NBUF][RD_MF_IMG_PAD];
     __shared__ __attribute__((aligned(16))) uint8_t s_xb[RD_MF_WAVES][RD_MF_XB_BYTES];
     __shared__ uint32_t s_pend[RD_MF_WAVES][RD_MF_PEND];
+    // packed words of up to four consecutive tiles of a stream, stored together: one 16-byte store per lane
+    // (1 KiB contiguous per wave) instead of four dword stores (round 1: a dword store per tile cost 20 % of
+    // the read bandwidth, profiles/r01_ubench_read_bw.txt)
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[RD_MF_WAVES][4][64];
+    constexpr bool LOADS = DBG != 1 && DBG != 4 && DBG != 5;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint8_t *img = s_img[wave];
-    uint8_t *xb = s_xb[wave] + 1024;
+    uint8_t *img0 = s_img[wave][0];
+    uint8_t *xb = s_xb[wave];
     uint32_t *mypend = s_pend[wave];
     uint32_t npend = 0;
 
@@ -216,58 +330,72 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         Ahi[d] = *(const rd_h8 *)g_mf_taps.v[0][d][lane];
         Alo[d] = *(const rd_h8 *)g_mf_taps.v[1][d][lane];
     }
-    // window addresses in the image
+    // a use in front of the loop: the wait for these six loads must not end up inside it, where it would
+    // be a vmcnt(0) that also drains the prefetched tiles in every iteration
+    asm volatile("" : "+v"(Ahi[0]), "+v"(Ahi[1]), "+v"(Ahi[2]), "+v"(Alo[0]), "+v"(Alo[1]), "+v"(Alo[2]));
+    // window addresses in the image (buffer 0; buffer 1 is RD_MF_IMG_PAD further)
+    const uint32_t img_addr = rd_lds_addr(img0);
     const uint32_t own = 16 + RD_MF_GROUP_BYTES * (n >> 3) + 16 * (n & 7) + 8 * h;
     const uint32_t prv = n == 0 ? 8 * h
                        : (n & 7) ? own + 16 * 55
                                  : 16 + RD_MF_GROUP_BYTES * ((n >> 3) - 1) + 16 * 63 + 8 * h;
-    // predecessor exchange: step b writes (g6, g7) of block b to xb[b][lane]; the lane that follows in
-    // time is (n, 1, b) after (n, 0, b), (n, 0, b) after (n, 1, b-1), (n, 0, 0) after (n-1, 1, 3), and
-    // (0, 0, 0) after lane 63 of the previous tile (carry slot, alternating with the tile parity).
-    const int xrd = h ? 16 * (lane - 32) : 16 * (lane + 32) - 1024;  // + 1024 b, b >= 1
-    uint32_t xrd0 = h ? 16 * (lane - 32) : lane ? 3072 + 16 * (lane + 31) : 4096 + 16;  // block 0 (end of tile)
-    uint32_t xwr3 = lane == 63 ? 4096 : 3072 + 16 * lane;                                  // step 3
-    const uint32_t rtoggle = lane == 0 ? 16u : 0u, wtoggle = lane == 63 ? 16u : 0u;
-    if (lane < 8) ((uint32_t *)(xb + 4096))[lane] = 0;  // carry slots: finite values from the start
+    // Predecessor exchange.  Step b writes (g6, g7) of block b; the lane that follows in time is
+    // (n, 1, b) after (n, 0, b), (n, 0, b) after (n, 1, b-1), (n, 0, 0) after (n-1, 1, 3), and (0, 0, 0) after
+    // lane 63 of the previous tile.  Buffers: X0 at 0, X1 and X3 at 1024, X2 at 2048 (X1 is dead when X3 is
+    // written), two carry slots at 3072 (lane 63's X3, alternating with the tile parity).
     const uint32_t xb_addr = rd_lds_addr(xb), pend_addr = rd_lds_addr(mypend);
+    const uint32_t stage_addr = rd_lds_addr(s_stage[wave]);
+    const uint32_t xw = xb_addr + 16 * lane;                       // + 0 / 1024 / 2048 for b = 0 / 1 / 2
+    uint32_t xw3 = xb_addr + (lane == 63 ? 3072 : 1024 + 16 * lane);
+    const uint32_t xr1 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 16 * (lane + 32));          // X1[l-32] | X0[l+32]
+    const uint32_t xr2 = xb_addr + (h ? 2048 + 16 * (lane - 32) : 1024 + 16 * (lane + 32));   // X2[l-32] | X1[l+32]
+    const uint32_t xr3 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 2048 + 16 * (lane + 32));   // X3[l-32] | X2[l+32]
+    uint32_t xr0 = xb_addr + (h ? 16 * (lane - 32) : lane ? 1024 + 16 * (lane + 31) : 3072 + 16);  // X0[l-32] | X3[l+31]
+    const uint32_t rtoggle = lane == 0 ? 16u : 0u, wtoggle = lane == 63 ? 16u : 0u;
+    if (lane < 8) ((uint32_t *)(xb + 3072))[lane] = 0;  // carry slots: finite values from the start
     const uint32_t psel = h ? 0x07030602u : 0x05010400u;
 
     const uint32_t nwaves = gridDim.x * RD_MF_WAVES;
-    // a wave's chunks: chunk index wg, wg + nwaves, ...; (s, ti) advances by one inside a chunk and by
-    // (nwaves - 1) * chunk + 1 between chunks
     const uint32_t jump = (nwaves - 1) * chunk + 1;
     const uint32_t jq = jump / tiles_per_stream, jr = jump % tiles_per_stream;
-    uint32_t tile = (blockIdx.x * RD_MF_WAVES + wave) * chunk;
-    uint32_t s = tile / tiles_per_stream, ti = tile % tiles_per_stream;
-    uint32_t inchunk = 0;
+    rd_mf_pos cur;
+    cur.tile = (blockIdx.x * RD_MF_WAVES + wave) * chunk;
+    cur.s = cur.tile / tiles_per_stream;
+    cur.ti = cur.tile % tiles_per_stream;
+    cur.inchunk = 0;
+    rd_mf_pos nx1 = rd_mf_next(cur, chunk, tiles_per_stream, jump, jq, jr);
+    uint32_t buf = 0;  // image buffer of the current tile (wave-uniform)
 
-    uint32_t st_word = 0;
-    uint32_t *st_ptr = nullptr;
-    if (DBG != 1 && tile < total_tiles) rd_mf_issue(lay, s, ti, img, lane);
-    while (tile < total_tiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile has landed in LDS
-        uint2 D[9];
-        D[0] = *(const uint2 *)(img + prv);
-#pragma unroll
-        for (int e = 0; e < 8; e++) D[e + 1] = *(const uint2 *)(img + own + 128 * e);
-        // window in registers: the image can take the next tile while this one is computed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (st_ptr) *st_ptr = st_word;  // previous tile's words, before the loads (they share vmcnt)
-        st_ptr = nullptr;
-        uint32_t ntile, ns, nti, ninchunk;
-        if (inchunk + 1 < chunk) {
-            ntile = tile + 1; ninchunk = inchunk + 1;
-            ns = s; nti = ti + 1;
-            if (nti >= tiles_per_stream) { nti = 0; ns++; }
-        } else {
-            ntile = tile + jump; ninchunk = 0;
-            ns = s + jq; nti = ti + jr;
-            if (nti >= tiles_per_stream) { nti -= tiles_per_stream; ns++; }
+    uint32_t nst = 0;             // tiles staged (wave-uniform)
+    uint32_t *st_base = nullptr;  // word 0 of the first staged tile
+    bool st_flush = false;        // the staged group ends here (next tile is not the next 64 words)
+    uint32_t rg_word = 0;         // a ragged last tile is stored word by word, predicated
+    uint32_t *rg_ptr = nullptr;
+    if (LOADS && cur.tile < total_tiles) rd_mf_issue(lay, cur.s, cur.ti, img0, lane);
+    if (NBUF == 2 && LOADS && nx1.tile < total_tiles) rd_mf_issue(lay, nx1.s, nx1.ti, img0 + RD_MF_IMG_PAD, lane);
+    while (cur.tile < total_tiles) {
+        const uint32_t tile = cur.tile, s = cur.s, ti = cur.ti, inchunk = cur.inchunk;
+        // this tile has landed when at most the next tile's five loads are outstanding (vmcnt counts in
+        // issue order; the previous iteration's word store and list flush are older or harmless)
+        if (NBUF == 2 && nx1.tile < total_tiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rd_u2v D[9];
+        const uint32_t boff = buf * RD_MF_IMG_PAD;
+        rd_mf_read_window(img_addr + boff + prv, img_addr + boff + own, D);
+        // the window is in registers: this buffer takes the tile after next
+        // stores of finished tiles go out here, before the loads (they share vmcnt, in issue order)
+        if (nst == 4 || (nst && st_flush)) {
+            rd_mf_store_staged(stage_addr, nst, st_base, lane, stflags);
+            nst = 0;
         }
-        if (DBG != 1 && ntile < total_tiles) rd_mf_issue(lay, ns, nti, img, lane);
+        if (rg_ptr) *rg_ptr = rg_word;
+        rg_ptr = nullptr;
+        const rd_mf_pos nx2 = rd_mf_next(nx1, chunk, tiles_per_stream, jump, jq, jr);
+        const rd_mf_pos fetch = NBUF == 2 ? nx2 : nx1;
+        if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane);
 
         uint32_t word = 0, fbytes = 0;
-        if (DBG == 2) {
+        if (DBG == 2 || DBG == 6) {
 #pragma unroll
             for (int j = 0; j < 9; j++) word ^= D[j].x ^ D[j].y;
         } else {
@@ -275,66 +403,83 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
 #pragma unroll
             for (int j = 0; j < 9; j++) bf[j] = rd_mf_frag(D[j]);
             rd_mf_state stt;
-            stt.F = 0.0f; stt.W = 0; stt.g0r = 0.0f; stt.g0i = 0.0f;
-            const uint32_t xw = xb_addr + 16 * lane, xr = xb_addr + xrd;
+            stt.W = 0; stt.fbytes = 0; stt.g0r = 0.0f; stt.g0i = 0.0f;
             float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 8 * h + 1) * 2 : nullptr;
             const int dleft = RD_TILE_SAMPLES - (64 * n + 8 * h + 1);  // outputs of this lane inside the tile
-            rd_mf_block<0, DBG>(Ahi, Alo, bf, xw, xr, stt, dg, dleft);
-            rd_mf_block<1, DBG>(Ahi, Alo, bf, xw, xr, stt, dg, dleft);
-            rd_mf_block<2, DBG>(Ahi, Alo, bf, xw, xr, stt, dg, dleft);
-            rd_mf_block<3, DBG>(Ahi, Alo, bf, xb_addr + xwr3 - 3072, xr, stt, dg, dleft);
+            rd_mf_block<0, DBG, 0>(Ahi, Alo, bf, xw, 0, stt, dg, dleft);
+            rd_mf_block<1, DBG, 1024>(Ahi, Alo, bf, xw, xr1, stt, dg, dleft);
+            rd_mf_block<2, DBG, 2048>(Ahi, Alo, bf, xw, xr2, stt, dg, dleft);
+            rd_mf_block<3, DBG, 0>(Ahi, Alo, bf, xw3, xr3, stt, dg, dleft);
             {   // block 0's first two numerators: W holds 30 bits, its bits 31, 30 are theirs
-                rd_f4v p = rd_lds_read16<0>(xb_addr + xrd0);
+                rd_f4v p = rd_lds_read16<0>(xr0);
                 rd_lds_wait(p);
-                stt.F = rd_max3abs(stt.F, p.x, p.y);
-                stt.F = rd_max3abs(stt.F, p.z, p.w);
-                const float n0 = rd_mf_num(p.x, p.y, p.z, p.w);
-                const float n1 = rd_mf_num(p.z, p.w, stt.g0r, stt.g0i);
-                stt.nmin[0] = rd_min3abs(stt.nmin[0], n0, n1);
+                float r0, r1;
+                const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, r0);
+                const float n1 = rd_mf_num(p.z, p.w, stt.g0r, stt.g0i, r1);
                 stt.W |= __builtin_bit_cast(uint32_t, n0) & 0x80000000u;
                 stt.W |= (__builtin_bit_cast(uint32_t, n1) >> 1) & 0x40000000u;
+                if (DBG == 0 || DBG == 3) {
+                    const float nm = rd_min3(3.0e38f, r0, r1);
+                    if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {
+                        float F = rd_max3abs(0.0f, p.x, p.y);
+                        F = rd_max3abs(F, p.z, p.w);
+                        F = rd_max3abs(F, stt.g0r, stt.g0i);
+                        if (!(nm > rd_mf_c0(F))) stt.fbytes |= 1u;
+                    }
+                }
             }
-            xrd0 ^= rtoggle;
-            xwr3 ^= wtoggle;
+            xr0 ^= rtoggle;
+            xw3 ^= wtoggle;
             word = __builtin_bitreverse32(stt.W);  // byte b = the signs of block b's group
-            const float thr = rd_mf_threshold(stt.F);
-#pragma unroll
-            for (int b = 0; b < 4; b++) fbytes |= (stt.nmin[b] > thr) ? 0u : (1u << (8 * b));  // NaN -> flagged
+            fbytes = stt.fbytes;
         }
         // The lane holds bytes (groups) 2b + h of its column's two words: gather word h of the column
         // (lanes n and n + 32 exchange halves), the flags likewise.
-        uint32_t gmask;
+        uint32_t gmask = 0;
         {
             const auto w2 = __builtin_amdgcn_permlane32_swap(word, word, false, false);  // [0]: half 0's, [1]: half 1's
             word = __builtin_amdgcn_perm(w2[1], w2[0], psel);
-            const auto f2 = __builtin_amdgcn_permlane32_swap(fbytes, fbytes, false, false);
-            const uint32_t fb = __builtin_amdgcn_perm(f2[1], f2[0], psel);
-            gmask = ((fb * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
         }
         const bool carry = inchunk > 0 && ti > 0;  // previous iteration = previous tile of this stream
         const uint32_t run = ti * 64 + 2 * n + h;  // word index in the stream
         const uint32_t t0 = run * RD_RUN;
+        const bool any_flag = rd_mf_any(fbytes != 0);
+        if (any_flag) {  // wave-uniform, rare
+            const auto f2 = __builtin_amdgcn_permlane32_swap(fbytes, fbytes, false, false);
+            const uint32_t fb = __builtin_amdgcn_perm(f2[1], f2[0], psel);
+            gmask = ((fb * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
+        }
         if (lane == 0) {
             if (ti == 0 && !lay.hist_mode) gmask = 0xFu;  // zero history: first run exact
             else if (!carry) gmask |= 1u;                 // no predecessors for the tile's first group
         }
         const bool ragged = (ti + 1 == tiles_per_stream) && (lay.n_samples % RD_TILE_SAMPLES) != 0;
-        if (!ragged) {
-            st_word = word;
-            st_ptr = &lay.bits[(size_t)s * lay.bits_stride + run];
+        if (DBG == 6) {
+            if (word == 0x12345678u) lay.bits[0] = word;  // keeps the loads alive, stores nothing
+        } else if (!ragged) {
+            if (nst == 0) {
+                st_base = &lay.bits[(size_t)s * lay.bits_stride + ti * 64];
+                // diagnostic (RD_K1_STFLAGS & 2): all stores land in the first MiB of the bits array
+                if (stflags & 2) st_base = &lay.bits[(((size_t)s * lay.bits_stride + ti * 64) & 0x3FFFFu) & ~255u];
+            }
+            rd_lds_write4(stage_addr + 256 * nst + 4 * (2 * n + h), word);  // the lane holds word 2n + h of the tile
+            nst++;
+            // the group goes on only if the next tile of this wave is the next 64 words of the same stream
+            const bool next_ragged = (nx1.ti + 1 == tiles_per_stream) && (lay.n_samples % RD_TILE_SAMPLES) != 0;
+            st_flush = !(nx1.tile < total_tiles && nx1.s == s && nx1.ti == ti + 1 && !next_ragged);
         } else if (t0 < lay.n_samples) {
             const uint32_t left = lay.n_samples - t0;
             if (left < RD_RUN) {
                 word &= (1u << left) - 1u;
                 gmask &= (1u << ((left + RD_GROUP - 1) / RD_GROUP)) - 1u;
             }
-            st_word = word;
-            st_ptr = &lay.bits[(size_t)s * lay.bits_stride + run];
+            rg_word = word;
+            rg_ptr = &lay.bits[(size_t)s * lay.bits_stride + run];
         } else {
             gmask = 0;
         }
-        if (DBG == 1 || DBG == 2) gmask = 0;
-        const uint64_t fm = __ballot(gmask != 0);
+        if (DBG == 1 || DBG == 2 || (DBG >= 4 && DBG != 7)) gmask = 0;  // (incl. 6)
+        const uint64_t fm = (any_flag || !carry) ? __ballot(gmask != 0) : 0;
         if (fm) {
             const uint32_t nf = (uint32_t)__popcll(fm);
             if (npend + nf > RD_MF_PEND) {
@@ -347,9 +492,12 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
                               ((uint32_t)((size_t)s * lay.bits_stride + run) << 4) | gmask);
             npend += nf;
         }
-        tile = ntile; s = ns; ti = nti; inchunk = ninchunk;
+        cur = nx1;
+        nx1 = nx2;
+        if (NBUF == 2) buf ^= 1;
     }
-    if (st_ptr) *st_ptr = st_word;
+    if (nst) rd_mf_store_staged(stage_addr, nst, st_base, lane, stflags);
+    if (rg_ptr) *rg_ptr = rg_word;
     if (npend) rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, lane);
 }
 
@@ -364,51 +512,65 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     const uint64_t total64 = (uint64_t)lay.n_streams * tps;
     if (total64 == 0) return;
     const uint32_t total = (uint32_t)total64;
-    static int dbg = -1, chunk_env = 0, per_cu_env = 0, n_cu = 0, per_cu_occ[4] = {0, 0, 0, 0};
+    static uint32_t stflags = 0;
+    static int dbg = -1, chunk_env = 0, per_cu_env = 0, n_cu = 0, nbuf = 2, per_cu_occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (dbg < 0) {
         dbg = rd_mf_env("RD_K1_DEBUG", 0);
         chunk_env = rd_mf_env("RD_K1_CHUNK", 0);
         per_cu_env = rd_mf_env("RD_K1_WGS_PER_CU", 0);
+        nbuf = rd_mf_env("RD_K1_NBUF", 2) == 1 ? 1 : 2;
+        stflags = (uint32_t)rd_mf_env("RD_K1_STFLAGS", 0);
         int dev = 0;
         hipGetDevice(&dev);
         hipDeviceProp_t prop;
         n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                    ? prop.multiProcessorCount : 256;
     }
-    const int variant = dbg_g ? 3 : (dbg == 1 || dbg == 2) ? dbg : 0;
+    const int variant = dbg_g ? 3 : (dbg == 1 || dbg == 2 || (dbg >= 4 && dbg <= 7)) ? dbg : 0;
     // persistent grid sized from the occupancy API (registers and LDS of the variant actually launched)
-    if (!per_cu_occ[variant]) {
+    if (!per_cu_occ[variant]) {  // (nbuf is fixed per process)
         int occ = 0;
         hipError_t e = hipErrorUnknown;
         switch (variant) {
-            case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<0>, RD_MF_WG, 0); break;
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<1>, RD_MF_WG, 0); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<2>, RD_MF_WG, 0); break;
-            default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<3>, RD_MF_WG, 0); break;
+            case 0: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<0, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<0, 2>, RD_MF_WG, 0)); break;
+            case 1: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<1, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<1, 2>, RD_MF_WG, 0)); break;
+            case 2: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<2, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<2, 2>, RD_MF_WG, 0)); break;
+            case 4: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<4, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<4, 2>, RD_MF_WG, 0)); break;
+            case 5: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<5, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<5, 2>, RD_MF_WG, 0)); break;
+            case 6: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<6, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<6, 2>, RD_MF_WG, 0)); break;
+            case 7: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<7, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<7, 2>, RD_MF_WG, 0)); break;
+            default: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<3, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<3, 2>, RD_MF_WG, 0)); break;
         }
         per_cu_occ[variant] = (e == hipSuccess && occ >= 1) ? (occ > 8 ? 8 : occ) : 2;
     }
     const int per_cu = (per_cu_env >= 1 && per_cu_env <= 8) ? per_cu_env : per_cu_occ[variant];
-    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : 6;
+    // default 12: a multiple of the 4-tile store groups that divides the 132 tiles of a 33-block stream
+    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : 12;
     if (chunk > total) chunk = total;
     const uint64_t chunks = (total64 + chunk - 1) / chunk;
     uint64_t wgs = (chunks + RD_MF_WAVES - 1) / RD_MF_WAVES;
     const uint64_t max_wgs = (uint64_t)n_cu * per_cu;
     if (wgs > max_wgs) wgs = max_wgs;
-#define RD_LAUNCH_MF(D)                                                                                              \
+#define RD_LAUNCH_MF2(D, NB)                                                                                         \
     do {                                                                                                             \
         if (ev_start || ev_stop)                                                                                     \
-            hipExtLaunchKernelGGL((k_demod_mfma<D>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, st, ev_start, ev_stop,  \
-                                  0, lay, tps, total, chunk, fix_list, fix_cap, counters, dbg_g);                    \
+            hipExtLaunchKernelGGL((k_demod_mfma<D, NB>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, st, ev_start,       \
+                                  ev_stop, 0, lay, tps, total, chunk, fix_list, fix_cap, counters, dbg_g, stflags);  \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_demod_mfma<D>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, st, lay, tps, total,       \
-                               chunk, fix_list, fix_cap, counters, dbg_g);                                           \
+            hipLaunchKernelGGL((k_demod_mfma<D, NB>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, st, lay, tps, total,   \
+                               chunk, fix_list, fix_cap, counters, dbg_g, stflags);                                  \
     } while (0)
+#define RD_LAUNCH_MF(D) do { if (nbuf == 1) RD_LAUNCH_MF2(D, 1); else RD_LAUNCH_MF2(D, 2); } while (0)
     if (variant == 3) RD_LAUNCH_MF(3);
     else if (variant == 1) RD_LAUNCH_MF(1);
     else if (variant == 2) RD_LAUNCH_MF(2);
+    else if (variant == 4) RD_LAUNCH_MF(4);
+    else if (variant == 5) RD_LAUNCH_MF(5);
+    else if (variant == 6) RD_LAUNCH_MF(6);
+    else if (variant == 7) RD_LAUNCH_MF(7);
     else RD_LAUNCH_MF(0);
 #undef RD_LAUNCH_MF
+#undef RD_LAUNCH_MF2
 }
 
 // Test hook (tests/test_gpu_mfma.py): run the kernel on host data, return the raw filter outputs g

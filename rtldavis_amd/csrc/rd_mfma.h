@@ -45,11 +45,23 @@
 // Exactness of the f32 accumulation: sum_m |hi_m| * 638 = 5 509 768 and sum_m |lo_m| * 638 <= 9 * 1024 * 638
 // = 5 879 808, both < 2^24 = 16 777 216 (times the common 2^-12, which only moves the exponent).
 
-// |num_hat - num| for num = -(a c + b d) evaluated as fma(-a, c, -(b*d)) on components with absolute
-// error e = E0 + 2^-24 |.| each and magnitudes <= F:  4 F e + 2 e^2 + 3 * 2^-24 F^2
-// <= F (4 E0 + 7 * 2^-24 F) + 2 e^2.  The threshold uses 2^-21 = 8 * 2^-24 for the F^2 term; the spare
-// 2^-24 F^2 covers 2 e^2 whenever F >= 1, the additive constant covers it below that (e < 0.011), and
-// the factor covers the fp32 rounding of this expression itself.
+// Error of a computed numerator.  Components x_hat = x + e, |e| <= E0 + 2^-24 |x_hat| (tap quantisation,
+// one rounding of the digit combine).  t1 = fl(b_hat d_hat), N_hat = fl(-a_hat c_hat - t1) (one fma):
+//   |a_hat c_hat - a c| <= E0 (|a_hat| + |c_hat|) + 2^-23 |a_hat c_hat| + (E0 + 2^-24 F)^2, same for b d;
+//   the two roundings add 2^-24 |b_hat d_hat| + 2^-24 |N_hat|;  |a_hat c_hat| <= |N_hat| (1 + 2^-23) + |t1|.
+// With F >= every |component| involved and (E0 + 2^-24 F_MAX)^2 < 0.031:
+//   |N_hat - N| <= 4 E0 F + 2^-22 |N_hat| + 2^-21 |t1| + 0.07,
+// so the sign of N_hat is the sign of the exact N whenever
+//   r := |N_hat| - 2^-21 |t1|  >  rd_mf_c0(F) := (4 E0 F + 0.07) * (1 + 2^-19)
+// (the factor covers the 2^-22 |N_hat| term and the fp32 rounding of r and of this expression).
+// rd_mf_threshold(F) = F (4 E0 + 2^-21 F) + 3e-4 is the cruder form |N_hat| > ... with |t1| <= F^2; kept for
+// the host-side model.
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__
+#else
+static inline
+#endif
+float rd_mf_c0(float F) { return (4.0f * RD_MF_E0 * F + 0.07f) * 1.000002f; }
 #if defined(__HIPCC__)
 __host__ __device__ __forceinline__
 #else
@@ -58,6 +70,14 @@ static inline
 float rd_mf_threshold(float F) {
     return (F * (4.0f * RD_MF_E0 + 4.76837158e-7f * F) + 3.0e-4f) * 1.000001f;
 }
+
+// The largest |component| of g any input can produce: 2^-12 * 638 * sum_m T_m = 2 754 468 (kernel units,
+// 127.6 byte units), and the threshold that goes with it (3.74e6 = 0.008 byte units squared): a numerator
+// above it has a certain sign whatever the signal level.
+#define RD_MF_F_MAX 2754500.0f
+#define RD_MF_THR_MAX 3.74e6f
+// rd_mf_c0(RD_MF_F_MAX) = 117 893: 2.5e-4 byte units squared
+#define RD_MF_C0_MAX 1.179e5f
 
 // element j of a lane's 8-element B fragment is byte RD_MF_ELEM(j) of the 8 window bytes the lane
 // reads: registers (b0,b2) (b1,b3) (b4,b6) (b5,b7) - the even bytes of a dword come out of one AND.

@@ -101,6 +101,12 @@ def bits_from_g(g: np.ndarray) -> np.ndarray:
     return (p > 0).astype(np.uint8)
 
 
+def c0(F: np.ndarray) -> np.ndarray:
+    """rd_mf_c0 in float32 arithmetic: what r = |num| - 2^-21 |b d| must exceed for a certain sign."""
+    F = F.astype(np.float32)
+    return (np.float32(4.0) * np.float32(E0) * F + np.float32(0.07)) * np.float32(1.000002)
+
+
 def threshold(F: np.ndarray) -> np.ndarray:
     """rd_mf_threshold in float32 arithmetic."""
     F = F.astype(np.float32)

@@ -84,22 +84,21 @@ def test_guard_band_covers_every_mismatch():
         n = bits.size
         a, b = gf_re[:n], gf_im[:n]          # g[t-1] for t = 1..n  (index t-1)
         c, d = gf_re[1: n + 1], gf_im[1: n + 1]
-        num = -(a.astype(np.float64) * c + b.astype(np.float64) * d)  # close enough to the fp32 fma pair
-        num32 = (np.float32(-1) * a * c - (b * d)).astype(np.float32)
+        t1 = (b * d).astype(np.float32)
+        # the kernel's fma: -a*c - t1 with one rounding (float64 holds the exact product and sum)
+        num32 = (-(a.astype(np.float64) * c.astype(np.float64)) - t1.astype(np.float64)).astype(np.float32)
         fast = np.signbit(num32).astype(np.uint8)
-        # groups of 8 samples t = 8k+1 .. (model of "min |num| over the group" against thr(F), F per 32 samples)
+        r = (np.abs(num32).astype(np.float64) - 4.76837158e-7 * np.abs(t1).astype(np.float64)).astype(np.float32)
+        # groups of 8 samples: min r over the group against c0(F), F = largest component the group used
         t = np.arange(1, n)
         F = np.maximum(np.maximum(np.abs(a), np.abs(b)), np.maximum(np.abs(c), np.abs(d)))[: n - 1]
         grp = (t // 8)
-        run = (t // 32)
-        Frun = np.zeros(run.max() + 1, dtype=np.float32)
-        np.maximum.at(Frun, run, F)
-        thr = M.threshold(Frun)[run]
-        flagged_sample = np.abs(num32[: n - 1]) <= thr
+        Fg = np.zeros(grp.max() + 1, dtype=np.float32)
+        np.maximum.at(Fg, grp, F)
+        flagged_sample = ~(r[: n - 1] > M.c0(Fg)[grp])
         flagged_group = np.zeros(grp.max() + 1, dtype=bool)
         np.logical_or.at(flagged_group, grp, flagged_sample)
         mism = fast[: n - 1] != bits[1:n]
         assert not np.any(mism & ~flagged_group[grp]), "a wrong sign outside the guard band"
         total_flagged += int(flagged_group.sum())
-        del num
     assert total_flagged > 0  # the +-1 LSB case does hit exact zeros

@@ -1,11 +1,13 @@
-# SQ counters of k_demod_bits under the bench load (own run: counters only)
+# SQ counters of the fused demod kernel under the bench load (own run: counters only).
+# usage: pmc_k1.sh [tag]   (environment such as RD_K1_IMPL / RD_K1_DEBUG is passed through)
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq
+TAG=${1:-sq}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-verify > $OUT.log 2>&1
 python3 - <<PY
 import csv, glob, collections, os
-root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_sq"
+root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_$TAG"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
