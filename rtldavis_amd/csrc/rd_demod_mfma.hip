@@ -38,8 +38,9 @@
 #define RD_MF_IMG_BYTES (16 + 4 * RD_MF_GROUP_BYTES)   // 4624
 #define RD_MF_IMG_PAD 4624
 // predecessor exchange: three buffers of 64 x 16 B, then two carry slots (tile parity)
-#define RD_MF_XB_BYTES (3 * 1024 + 32)
-#define RD_MF_PEND 64
+// + the offset constant (four copies); a multiple of 32 so that XOR 16 toggles between the two carry slots
+#define RD_MF_XB_BYTES (3 * 1024 + 32 + 32)
+#define RD_MF_PEND 32
 
 typedef _Float16 rd_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
@@ -53,23 +54,14 @@ static const rd_mf_taps h_mf_taps = rd_mf_make_taps();
 
 extern "C" void rd_debug_mfma_taps(uint16_t *out) { memcpy(out, &h_mf_taps, sizeof h_mf_taps); }
 
-// two bytes (already isolated in the low byte of each half: an f16 subnormal b * 2^-24 each) ->
-// (5 b - 637) * 2^-12 as packed f16, exact: one v_pk_fma_f16
-__device__ __forceinline__ uint32_t rd_mf_center(uint32_t two) {
-    const rd_h2 x = __builtin_bit_cast(rd_h2, two);
-    const rd_h2 a = {(_Float16)20480.0f, (_Float16)20480.0f};                    // 5 * 2^12
-    const rd_h2 c = {(_Float16)(-637.0f / 4096.0f), (_Float16)(-637.0f / 4096.0f)};
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(x, a, c));
-}
-
-// the lane's 8 window bytes of one k-step -> B fragment (element order RD_MF_ELEM)
+// the lane's 8 window bytes of one k-step -> B fragment (element order RD_MF_ELEM).  A byte in the low
+// half of a 16-bit lane IS the f16 subnormal k * 2^-24: isolating the bytes is the whole conversion.
 __device__ __forceinline__ rd_h8 rd_mf_frag(rd_u2v d) {
     rd_u4v v;
-    // bytes 1 and 3 of a dword into the low bytes of the two halves: one v_perm_b32 (selector 0x0c = 0x00)
-    v.x = rd_mf_center(d.x & 0x00FF00FFu);
-    v.y = rd_mf_center(__builtin_amdgcn_perm(0u, d.x, 0x0c030c01u));
-    v.z = rd_mf_center(d.y & 0x00FF00FFu);
-    v.w = rd_mf_center(__builtin_amdgcn_perm(0u, d.y, 0x0c030c01u));
+    v.x = d.x & 0x00FF00FFu;                                // bytes 0, 2
+    v.y = __builtin_amdgcn_perm(0u, d.x, 0x0c030c01u);      // bytes 1, 3 (selector 0x0c = 0x00)
+    v.z = d.y & 0x00FF00FFu;
+    v.w = __builtin_amdgcn_perm(0u, d.y, 0x0c030c01u);
     return __builtin_bit_cast(rd_h8, v);
 }
 
@@ -138,29 +130,42 @@ __device__ __forceinline__ bool rd_mf_any(bool c) { return __ballot(c) != 0; }
 // One 16-output block of the tile: 6 MFMAs, the digit combine, then this lane's group of 8 signs.
 // xw + WOFF: LDS address this lane's (g6, g7) go to; xr: where its predecessors' are.
 template <int B, int DBG, int WOFF>
-__device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_h8 (&bf)[9],
-                                            uint32_t xw, uint32_t xr, rd_mf_state &st, float *dg, int dleft) {
+__device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_u2v (&D)[9],
+                                            rd_h8 (&bf)[3], uint32_t dc_addr, uint32_t xw, uint32_t xr,
+                                            rd_mf_state &st, float *dg, int dleft) {
     const rd_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the hi accumulator starts at -D_hi in all sixteen positions (four broadcast reads, in flight under
+    // the fragment preparation)
+    rd_f4v c0, c1, c2, c3;
+    if (DBG != 4)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4"
+                     : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(dc_addr) : "memory");
+    // fragments of k-steps 2B, 2B+1, 2B+2 of the window: the first one is the previous block's last
+    if (B == 0) bf[0] = rd_mf_frag(D[0]); else bf[0] = bf[2];
+    bf[1] = rd_mf_frag(D[2 * B + 1]);
+    bf[2] = rd_mf_frag(D[2 * B + 2]);
     // The six MFMAs go out as one burst with no vector instruction between them: a wave then sits in the
     // matrix pipe's queue for ~192 cycles while the other waves of the SIMD issue their VALU work, instead
     // of every wave stalling at an MFMA every few instructions (in-order issue: measured 1450 -> ... cycles/tile)
     __builtin_amdgcn_sched_barrier(0);
     rd_f16v ah, al;
     if (DBG == 4) {  // ablation: no matrix pipe, the vector work on stand-in values
-        const rd_u4v q0 = __builtin_bit_cast(rd_u4v, bf[2 * B]), q1 = __builtin_bit_cast(rd_u4v, bf[2 * B + 1]),
-                     q2 = __builtin_bit_cast(rd_u4v, bf[2 * B + 2]);
+        const rd_u4v q0 = __builtin_bit_cast(rd_u4v, bf[0]), q1 = __builtin_bit_cast(rd_u4v, bf[1]),
+                     q2 = __builtin_bit_cast(rd_u4v, bf[2]);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             ah[i] = __builtin_bit_cast(float, (i & 8 ? q1 : q0)[i & 3] | 0x3f000000u) + (float)i;
             al[i] = __builtin_bit_cast(float, (i & 8 ? q2 : q1)[i & 3] | 0x3f000000u);
         }
     } else {
-        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[0], bf[2 * B], zero, 0, 0, 0);
-        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], bf[2 * B], zero, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], bf[2 * B + 1], ah, 0, 0, 0);
-        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], bf[2 * B + 1], al, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2 * B + 2], ah, 0, 0, 0);
-        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2 * B + 2], al, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
+        const rd_f16v dc = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[0], bf[0], dc, 0, 0, 0);  // C = -D_hi: the -127.4 offset
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], bf[0], zero, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], bf[1], ah, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], bf[1], al, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2], ah, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2], al, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (DBG == 5) {  // ablation: the matrix pipe with next to no vector work behind it
@@ -305,10 +310,11 @@ template <int DBG, int NBUF>
 __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
                                                          uint32_t chunk, uint32_t *fix_list, uint32_t fix_cap,
                                                          uint32_t *counters, float *dbg_g, uint32_t stflags) {
-    // NBUF = 2: two image buffers per wave, while tile i is computed tiles i+1 and i+2 are in flight
-    // (3 workgroups per CU); NBUF = 1: one buffer, tile i+1 in flight (4 workgroups per CU).
+    // NBUF = 1 (default): one image buffer, tile i+1 in flight while tile i is computed, 4 workgroups per CU.
+    // NBUF = 2 (RD_K1_NBUF=2): two buffers, tiles i+1 and i+2 in flight, 3 workgroups per CU - measured slower
+    // (0.54 vs 0.53 ms: the fourth wave per SIMD is worth more than the second tile in flight).
     __shared__ __attribute__((aligned(16))) uint8_t s_img[RD_MF_WAVES][NBUF][RD_MF_IMG_PAD];
-    __shared__ __attribute__((aligned(16))) uint8_t s_xb[RD_MF_WAVES][RD_MF_XB_BYTES];
+    __shared__ __attribute__((aligned(32))) uint8_t s_xb[RD_MF_WAVES][RD_MF_XB_BYTES];
     __shared__ uint32_t s_pend[RD_MF_WAVES][RD_MF_PEND];
     // packed words of up to four consecutive tiles of a stream, stored together: one 16-byte store per lane
     // (1 KiB contiguous per wave) instead of four dword stores (round 1: a dword store per tile cost 20 % of
@@ -353,6 +359,9 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
     uint32_t xr0 = xb_addr + (h ? 16 * (lane - 32) : lane ? 1024 + 16 * (lane + 31) : 3072 + 16);  // X0[l-32] | X3[l+31]
     const uint32_t rtoggle = lane == 0 ? 16u : 0u, wtoggle = lane == 63 ? 16u : 0u;
     if (lane < 8) ((uint32_t *)(xb + 3072))[lane] = 0;  // carry slots: finite values from the start
+    // -D_hi * 2^-24 (the -127.4 offset): read into all sixteen positions of the hi accumulator in front of
+    // every block's MFMAs - from LDS rather than from a 16-register tuple held for the whole kernel
+    if (lane < 4) ((float *)(xb + 3104))[lane] = -(float)RD_MF_DHI / 16777216.0f;
     const uint32_t psel = h ? 0x07030602u : 0x05010400u;
 
     const uint32_t nwaves = gridDim.x * RD_MF_WAVES;
@@ -399,17 +408,15 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
 #pragma unroll
             for (int j = 0; j < 9; j++) word ^= D[j].x ^ D[j].y;
         } else {
-            rd_h8 bf[9];
-#pragma unroll
-            for (int j = 0; j < 9; j++) bf[j] = rd_mf_frag(D[j]);
+            rd_h8 bf[3];
             rd_mf_state stt;
             stt.W = 0; stt.fbytes = 0; stt.g0r = 0.0f; stt.g0i = 0.0f;
             float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 8 * h + 1) * 2 : nullptr;
             const int dleft = RD_TILE_SAMPLES - (64 * n + 8 * h + 1);  // outputs of this lane inside the tile
-            rd_mf_block<0, DBG, 0>(Ahi, Alo, bf, xw, 0, stt, dg, dleft);
-            rd_mf_block<1, DBG, 1024>(Ahi, Alo, bf, xw, xr1, stt, dg, dleft);
-            rd_mf_block<2, DBG, 2048>(Ahi, Alo, bf, xw, xr2, stt, dg, dleft);
-            rd_mf_block<3, DBG, 0>(Ahi, Alo, bf, xw3, xr3, stt, dg, dleft);
+            rd_mf_block<0, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw, 0, stt, dg, dleft);
+            rd_mf_block<1, DBG, 1024>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr1, stt, dg, dleft);
+            rd_mf_block<2, DBG, 2048>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr2, stt, dg, dleft);
+            rd_mf_block<3, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw3, xr3, stt, dg, dleft);
             {   // block 0's first two numerators: W holds 30 bits, its bits 31, 30 are theirs
                 rd_f4v p = rd_lds_read16<0>(xr0);
                 rd_lds_wait(p);
@@ -513,12 +520,12 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     if (total64 == 0) return;
     const uint32_t total = (uint32_t)total64;
     static uint32_t stflags = 0;
-    static int dbg = -1, chunk_env = 0, per_cu_env = 0, n_cu = 0, nbuf = 2, per_cu_occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static int dbg = -1, chunk_env = 0, per_cu_env = 0, n_cu = 0, nbuf = 1, per_cu_occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (dbg < 0) {
         dbg = rd_mf_env("RD_K1_DEBUG", 0);
         chunk_env = rd_mf_env("RD_K1_CHUNK", 0);
         per_cu_env = rd_mf_env("RD_K1_WGS_PER_CU", 0);
-        nbuf = rd_mf_env("RD_K1_NBUF", 2) == 1 ? 1 : 2;
+        nbuf = rd_mf_env("RD_K1_NBUF", 1) == 2 ? 2 : 1;
         stflags = (uint32_t)rd_mf_env("RD_K1_STFLAGS", 0);
         int dev = 0;
         hipGetDevice(&dev);

@@ -7,20 +7,24 @@
 //    f[t] = j^(t-9) g[t] with the SHIFT-INVARIANT complex-tap filter g[t] = sum_m (c_m j^m) x[t-9+m],
 //    and the numerator of py:89, Im(f[t-1] conj f[t]), equals -Re(g[t-1] conj g[t]).  So
 //        bit[t] = signbit( -(g_re[t-1] g_re[t] + g_im[t-1] g_im[t]) ).
-// 2. Everything is an integer.  x = (k - 127.4)/127.6 = U/638 with U = 5k - 637, and the taps are
-//    replaced by T_m = round(S c_m) for a scale S chosen so that all five distinct S c_m lie within
-//    0.02 of an integer (found by search; the sign of the numerator is scale invariant).  With
-//    T = 2048 hi + lo (hi <= 1974, lo in [-1024, 1023]) both digits and U are exact in f16, every
-//    product and every partial sum of  sum_m dig_m U_m  is an integer below 2^24 (bounds below), so
-//    v_mfma_f32_32x32x16_f16 accumulates it EXACTLY in f32 whatever its internal order, and
-//        G[t] = 2048 * (sum hi U) + (sum lo U)     (one fma, one rounding)
-//    is the FIR output in units of 2^-12 * 5 S / 1 byte-unit.  The only error against the true
-//    (real arithmetic) g is the tap quantisation, |T_m - S c_m| summed over the nine taps:
-//    RD_MF_E0 below, 4.9e-7 byte units - 70 times below the fp32 VALU path's rigorous bound - plus the
-//    2^-24 relative rounding of that one fma.
+// 2. Everything is an integer.  x = (k - 127.4)/127.6 for a byte k, and the taps are replaced by
+//    T_m = round(S c_m) for a scale S chosen (by search) so that all five distinct S c_m lie within 0.03 of an
+//    integer AND D = 127.4 * (2 T_0 - 2 T_2 + T_4), the response of both components to the -127.4 offset, lies
+//    within 3.6 of 2048 * D_hi with D_hi an integer (the sign of the numerator is scale invariant).  With
+//    T = 2048 hi + lo (hi <= 2038, lo in [-1024, 1023]) both digits are exact in f16, and so is the raw byte:
+//    read as an f16 BIT PATTERN a byte k is the subnormal k * 2^-24, which v_mfma_f32_32x32x16_f16 takes at
+//    face value and at full rate (tools/ubench/mfma_subnormal.hip).  Every product and every partial sum of
+//    sum_m dig_m k_m  (and of the hi sum less D_hi) is an integer below 2^24 times 2^-24, so the matrix pipe
+//    accumulates it EXACTLY in f32 whatever its internal order, and
+//        G[t] = 2048 * (sum hi k - D_hi) + (sum lo k)     (one fma, one rounding)
+//    is the FIR output of the centred samples in units of 2^-24 S per byte unit.  The only error against
+//    the true (real arithmetic) g is the tap quantisation |T_m - S c_m| summed over the nine taps times
+//    |k| <= 255, plus the 3.6 of the offset: RD_MF_E0 below, 1.6e-6 byte units - 20 times below the fp32
+//    VALU path's rigorous bound - plus the 2^-24 relative rounding of that one fma.
 // 3. Shape.  B operand = raw samples: lane (column n = lane & 31, half h = lane >> 5) holds 8 bytes
-//    of its column's window per 16-byte k-step, converted to f16 (5k-637) * 2^-12 by one mask and one
-//    v_pk_fma_f16 per two bytes (a byte b read as an f16 bit pattern is the subnormal b * 2^-24).
+//    of its column's window per 16-byte k-step; a mask isolates the even bytes of a dword as two f16
+//    patterns, one v_perm_b32 the odd ones - no conversion arithmetic at all.  The offset enters as the C
+//    operand of the first hi-digit MFMA of a block (a constant 16-register tuple).
 //    A operand = constant tap matrix (32 rows = 16 outputs x {re, im}, 16 k), six fragments
 //    (3 k-steps x 2 digits) kept in registers.  One 16-output block of 32 columns costs 6 MFMAs;
 //    a 2048-sample tile 24.  The rows are permuted so that a lane's 16 accumulator registers are
@@ -31,53 +35,53 @@
 #pragma once
 #include <stdint.h>
 
-#define RD_MF_SCALE 17683709.98098367
-#define RD_MF_T0 312688
-#define RD_MF_T1 851848
-#define RD_MF_T2 2164923
-#define RD_MF_T3 3490915
-#define RD_MF_T4 4042962
-// sum_m |T_m - S c_m| over the nine taps (exact rational arithmetic, tests/test_mfma_model.py): 0.0677192
-// E0 = 2^-12 * 638 * that = 0.010548 in units of G; 1.5 % margin
-#define RD_MF_E0 0.0107f
-// G units per byte unit of f: 2^-12 * 5 * S
-#define RD_MF_G_PER_BYTE (5.0 * RD_MF_SCALE / 4096.0)
-// Exactness of the f32 accumulation: sum_m |hi_m| * 638 = 5 509 768 and sum_m |lo_m| * 638 <= 9 * 1024 * 638
-// = 5 879 808, both < 2^24 = 16 777 216 (times the common 2^-12, which only moves the exponent).
+#define RD_MF_SCALE 18255980.028508045
+#define RD_MF_T0 322807
+#define RD_MF_T1 879415
+#define RD_MF_T2 2234983
+#define RD_MF_T3 3603886
+#define RD_MF_T4 4173798
+// 127.4 * (2 T0 - 2 T2 + T4) = 44 519 420.4 = 2048 * 21738 - 3.6
+#define RD_MF_DHI 21738
+// sum_m |T_m - S c_m| over the nine taps (exact rational arithmetic, tests/test_mfma_model.py): 0.0980034
+// E0 = 2^-24 * (255 * that + 3.6) = 1.7041e-6 in units of G; 1.5 % margin
+#define RD_MF_E0 1.73e-6f
+// G units per byte unit of f: 2^-24 * S
+#define RD_MF_G_PER_BYTE (RD_MF_SCALE / 16777216.0)
+// Exactness of the f32 accumulation: sum_m |hi_m| * 255 + D_hi = 2 294 808 and sum_m |lo_m| * 255 <= 9 * 1024 * 255
+// = 2 350 080, both < 2^24 = 16 777 216 (times the common 2^-24, which only moves the exponent).
 
 // Error of a computed numerator.  Components x_hat = x + e, |e| <= E0 + 2^-24 |x_hat| (tap quantisation,
 // one rounding of the digit combine).  t1 = fl(b_hat d_hat), N_hat = fl(-a_hat c_hat - t1) (one fma):
 //   |a_hat c_hat - a c| <= E0 (|a_hat| + |c_hat|) + 2^-23 |a_hat c_hat| + (E0 + 2^-24 F)^2, same for b d;
 //   the two roundings add 2^-24 |b_hat d_hat| + 2^-24 |N_hat|;  |a_hat c_hat| <= |N_hat| (1 + 2^-23) + |t1|.
-// With F >= every |component| involved and (E0 + 2^-24 F_MAX)^2 < 0.031:
-//   |N_hat - N| <= 4 E0 F + 2^-22 |N_hat| + 2^-21 |t1| + 0.07,
+// With F >= every |component| involved and (E0 + 2^-24 F_MAX)^2 < 1.1e-10:
+//   |N_hat - N| <= 4 E0 F + 2^-22 |N_hat| + 2^-21 |t1| + 3e-10,
 // so the sign of N_hat is the sign of the exact N whenever
-//   r := |N_hat| - 2^-21 |t1|  >  rd_mf_c0(F) := (4 E0 F + 0.07) * (1 + 2^-19)
+//   r := |N_hat| - 2^-21 |t1|  >  rd_mf_c0(F) := (4 E0 F + 3e-10) * (1 + 2^-19)
 // (the factor covers the 2^-22 |N_hat| term and the fp32 rounding of r and of this expression).
-// rd_mf_threshold(F) = F (4 E0 + 2^-21 F) + 3e-4 is the cruder form |N_hat| > ... with |t1| <= F^2; kept for
+// rd_mf_threshold(F) = F (4 E0 + 2^-21 F) + 3e-10 is the cruder form |N_hat| > ... with |t1| <= F^2; kept for
 // the host-side model.
 #if defined(__HIPCC__)
 __host__ __device__ __forceinline__
 #else
 static inline
 #endif
-float rd_mf_c0(float F) { return (4.0f * RD_MF_E0 * F + 0.07f) * 1.000002f; }
+float rd_mf_c0(float F) { return (4.0f * RD_MF_E0 * F + 3.0e-10f) * 1.000002f; }
 #if defined(__HIPCC__)
 __host__ __device__ __forceinline__
 #else
 static inline
 #endif
 float rd_mf_threshold(float F) {
-    return (F * (4.0f * RD_MF_E0 + 4.76837158e-7f * F) + 3.0e-4f) * 1.000001f;
+    return (F * (4.0f * RD_MF_E0 + 4.76837158e-7f * F) + 3.0e-10f) * 1.000001f;
 }
 
-// The largest |component| of g any input can produce: 2^-12 * 638 * sum_m T_m = 2 754 468 (kernel units,
-// 127.6 byte units), and the threshold that goes with it (3.74e6 = 0.008 byte units squared): a numerator
-// above it has a certain sign whatever the signal level.
-#define RD_MF_F_MAX 2754500.0f
-#define RD_MF_THR_MAX 3.74e6f
-// rd_mf_c0(RD_MF_F_MAX) = 117 893: 2.5e-4 byte units squared
-#define RD_MF_C0_MAX 1.179e5f
+// The largest |component| of g any input can produce: 2^-24 * 127.6 * sum_m T_m = 138.85 (kernel units,
+// 127.6 byte units), and rd_mf_c0 of it, 9.61e-4 (8e-4 byte units squared): an r above that means a
+// certain sign whatever the signal level.
+#define RD_MF_F_MAX 138.9f
+#define RD_MF_C0_MAX 9.62e-4f
 
 // element j of a lane's 8-element B fragment is byte RD_MF_ELEM(j) of the 8 window bytes the lane
 // reads: registers (b0,b2) (b1,b3) (b4,b6) (b5,b7) - the even bytes of a dword come out of one AND.

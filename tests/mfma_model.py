@@ -6,6 +6,7 @@ fragment, the documented lane maps of v_mfma_f32_32x32x16_f16 (A[row = lane & 31
 B[k][col = lane & 31], D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31]) and the tap
 matrix the library exports (rd_debug_mfma_taps).  Everything is an integer, so the model is exact;
 tests compare it with a direct evaluation of g[t] = sum_m T_m j^m U[t-9+m] and with the oracle.
+The raw byte k enters the matrix pipe as the f16 subnormal k * 2^-24; the -127.4 offset is the constant DHI.
 """
 from __future__ import annotations
 
@@ -14,11 +15,13 @@ from fractions import Fraction
 import numpy as np
 
 TILE = 2048
-SCALE = 17683709.98098367
-T = (312688, 851848, 2164923, 3490915, 4042962)
+SCALE = 18255980.028508045
+T = (322807, 879415, 2234983, 3603886, 4173798)
+DHI = 21738  # 127.4 * (2 T0 - 2 T2 + T4) = 2048 * DHI - 3.6
 C12 = (17682261285, 48171339939, 122424706672, 197408519126, 228626345955)  # fir9 taps * 1e12 (dsp.py:56-69)
 ELEM = (0, 2, 1, 3, 4, 6, 5, 7)  # element j of a B fragment = byte ELEM[j] of the lane's 8 window bytes
-E0 = 0.0107  # RD_MF_E0
+E0 = 1.73e-6  # RD_MF_E0 (kernel units: 2^-24 S per byte unit)
+UNIT = 2.0 ** -24  # a raw byte read as an f16 bit pattern
 
 
 def taps_from_lib() -> np.ndarray:
@@ -36,29 +39,32 @@ def tap_error_sum() -> Fraction:
     return 2 * sum(eps[:4]) + eps[4]
 
 
-def centred(raw: np.ndarray) -> np.ndarray:
-    """U = 5 k - 637 per byte (x = U / 638, dsp.py:26)."""
-    return 5 * raw.astype(np.int64) - 637
-
-
-def g_direct(raw: np.ndarray, hist: np.ndarray | None = None) -> np.ndarray:
-    """g[t] = sum_m T_m j^m U[t-9+m] for t = 0..n (n+1 values), complex with integer parts.
-    Samples before the stream are `hist` bytes (interleaved, oldest first) or - with no history -
-    the zero state y = 0 of dsp.py:131."""
-    u = centred(raw)
-    z = (u[0::2] + 1j * u[1::2])
-    if hist is None:
-        pre = np.zeros(9, dtype=np.complex128)
-    else:
-        uh = centred(hist)
-        pre = (uh[0::2] + 1j * uh[1::2])[-9:]
-    zp = np.concatenate([pre, z])
-    n = z.size
+def _fir(zp: np.ndarray, n: int) -> np.ndarray:
     taps = [T[m if m <= 4 else 8 - m] * (1j ** m) for m in range(9)]
     g = np.zeros(n + 1, dtype=np.complex128)
     for m in range(9):
-        g += taps[m] * zp[m: m + n + 1] if m + n + 1 <= zp.size else 0
+        g += taps[m] * zp[m: m + n + 1]
     return g
+
+
+def g_true(raw: np.ndarray, hist: np.ndarray | None = None) -> np.ndarray:
+    """sum_m T_m j^m (k - 127.4)[t-9+m] for t = 0..n: the quantised-tap filter on the CENTRED samples
+    (x = (k - 127.4) / 127.6, dsp.py:26).  Samples before the stream are `hist` bytes (interleaved, oldest
+    first) or - with no history - the zero state y = 0 of dsp.py:131."""
+    z = (raw[0::2].astype(np.float64) - 127.4) + 1j * (raw[1::2].astype(np.float64) - 127.4)
+    if hist is None:
+        pre = np.zeros(9, dtype=np.complex128)
+    else:
+        pre = ((hist[0::2].astype(np.float64) - 127.4) + 1j * (hist[1::2].astype(np.float64) - 127.4))[-9:]
+    return _fir(np.concatenate([pre, z]), z.size)
+
+
+def g_direct(raw: np.ndarray, hist: np.ndarray) -> np.ndarray:
+    """What the kernel computes, as exact integers: sum_m T_m j^m k[t-9+m] - 2048 DHI (1 + j) for t = 0..n
+    (multiply by UNIT for kernel units).  Needs real bytes as history (>= 9 samples)."""
+    z = raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64)
+    pre = (hist[0::2].astype(np.float64) + 1j * hist[1::2].astype(np.float64))[-9:]
+    return _fir(np.concatenate([pre, z]), z.size) - 2048.0 * DHI * (1 + 1j)
 
 
 def model_tile(win: np.ndarray, taps: np.ndarray) -> np.ndarray:
@@ -66,7 +72,7 @@ def model_tile(win: np.ndarray, taps: np.ndarray) -> np.ndarray:
     tile's 4096 bytes.  Returns g (complex, integer parts) for outputs t = 1 .. 2048 of the tile
     (index t - 1), i.e. lane (n, h), block b, register pair r -> t = 64 n + 16 b + 8 h + 1 + r."""
     assert win.size == 16 + 2 * TILE
-    u = centred(win).astype(np.float64)
+    u = win.astype(np.float64)
     out = np.zeros(TILE, dtype=np.complex128)
     lanes = np.arange(64)
     n, h = lanes & 31, lanes >> 5
@@ -84,7 +90,7 @@ def model_tile(win: np.ndarray, taps: np.ndarray) -> np.ndarray:
                 for lane in lanes:
                     amat[lane & 31, 8 * (lane >> 5): 8 * (lane >> 5) + 8] = taps[dig, d, lane]
                 acc[dig] += amat @ bmat
-        full = 2048.0 * acc[0] + acc[1]
+        full = 2048.0 * (acc[0] - DHI) + acc[1]
         for lane in lanes:
             for reg in range(16):
                 row = (reg & 3) + 8 * (reg >> 2) + 4 * h[lane]
@@ -104,11 +110,11 @@ def bits_from_g(g: np.ndarray) -> np.ndarray:
 def c0(F: np.ndarray) -> np.ndarray:
     """rd_mf_c0 in float32 arithmetic: what r = |num| - 2^-21 |b d| must exceed for a certain sign."""
     F = F.astype(np.float32)
-    return (np.float32(4.0) * np.float32(E0) * F + np.float32(0.07)) * np.float32(1.000002)
+    return (np.float32(4.0) * np.float32(E0) * F + np.float32(3.0e-10)) * np.float32(1.000002)
 
 
 def threshold(F: np.ndarray) -> np.ndarray:
     """rd_mf_threshold in float32 arithmetic."""
     F = F.astype(np.float32)
-    return ((F * (np.float32(4.0) * np.float32(E0) + np.float32(4.76837158e-7) * F) + np.float32(3.0e-4))
+    return ((F * (np.float32(4.0) * np.float32(E0) + np.float32(4.76837158e-7) * F) + np.float32(3.0e-10))
             * np.float32(1.000001))

@@ -58,7 +58,8 @@ def check(streams: np.ndarray, hist=None, chunk=6):
     fl = flagged_groups(fix, ns, words)
     for s in range(ns):
         h = None if hist is None else hist[s]
-        gd = M.g_direct(streams[s], hist=h) / 4096.0           # exact values, kernel units; index t = 0..n
+        # exact values in kernel units, index t = 0..n; without history the first outputs see made-up bytes
+        gd = M.g_direct(streams[s], h if h is not None else np.full(18, 127, np.uint8)) * M.UNIT
         want = np.stack([gd.real, gd.imag], axis=1).astype(np.float32)  # one rounding, like the kernel's fma
         got = g[s]
         tl = np.arange(got.shape[0]) % M.TILE

@@ -20,11 +20,14 @@ def test_tap_scale_and_error_constant():
     for t, c in zip(M.T, M.C12):
         assert t == round(M.SCALE * c / 1e12)
     eps = M.tap_error_sum()
-    assert abs(float(eps) - 0.0677192) < 1e-6
-    e0 = float(eps) * 638 / 4096
+    assert abs(float(eps) - 0.0980034) < 1e-6
+    # the -127.4 offset: D = 127.4 (2 T0 - 2 T2 + T4) misses 2048 DHI by 3.6
+    d = 127.4 * (2 * M.T[0] - 2 * M.T[2] + M.T[4])
+    assert abs(abs(d - 2048 * M.DHI) - 3.6) < 1e-6
+    e0 = (float(eps) * 255 + 3.6) / 2 ** 24
     assert e0 < M.E0 < 1.02 * e0  # RD_MF_E0 bounds it with < 2 % slack
-    # in byte units of f: 70 times below the fp32 VALU path's 3.3e-5
-    assert M.E0 / (5 * M.SCALE / 4096) < 5.0e-7
+    # in byte units of f: 20 times below the fp32 VALU path's 3.3e-5
+    assert M.E0 / (M.SCALE / 2 ** 24) < 1.7e-6
 
 
 def test_digits_are_f16_exact_and_sums_stay_below_2_24():
@@ -36,7 +39,7 @@ def test_digits_are_f16_exact_and_sums_stay_below_2_24():
         for d in range(3):
             for lane in range(64):
                 rows[lane & 31] += np.abs(taps[dig, d, lane]).sum()
-        assert rows.max() * 638 < 2 ** 24, (dig, rows.max() * 638)
+        assert rows.max() * 255 + M.DHI < 2 ** 24, (dig, rows.max() * 255)
     # hi * 2048 + lo reproduces the signed integer taps
     full = 2048 * taps[0] + taps[1]
     assert set(np.unique(np.abs(full)).astype(np.int64)) == {0, *M.T}
@@ -52,14 +55,14 @@ def test_lane_maps_reproduce_the_direct_filter():
         got = M.model_tile(raw, taps)
         # history for the direct form: the 16-byte halo (8 samples) behind one filler sample; g[1], the
         # first output the kernel computes, starts exactly at the halo (samples -8 .. 0)
-        want = M.g_direct(raw[16:], hist=np.concatenate([np.full(2, 127, np.uint8), raw[:16]]))
+        want = M.g_direct(raw[16:], np.concatenate([np.full(2, 127, np.uint8), raw[:16]]))
         assert np.array_equal(got, want[1: M.TILE + 1]), trial
 
 
 def test_rotation_free_numerator_matches_the_oracle():
     raw = synth_stream(3, n_samples=4 * 8192)
     _, _, bits = O.demod_stream_oneshot(raw)
-    g = M.g_direct(raw)  # g[t], t = 0..n with zero history
+    g = M.g_true(raw)  # g[t], t = 0..n with zero history
     gm1 = np.concatenate([[0], g[:-1]])  # g[t-1] for t = 0..n
     p = (gm1 * np.conj(g)).real[: bits.size]
     mine = (p > 0).astype(np.uint8)
@@ -78,7 +81,7 @@ def test_guard_band_covers_every_mismatch():
     total_flagged = 0
     for raw in cases:
         _, _, bits = O.demod_stream_oneshot(raw)
-        g = M.g_direct(raw) / 4096.0  # kernel units
+        g = M.g_true(raw) * M.UNIT  # kernel units (the 3.6 of the offset is part of E0)
         gf_re = g.real.astype(np.float32)
         gf_im = g.imag.astype(np.float32)
         n = bits.size
