@@ -120,6 +120,25 @@ int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_comple
  */
 int rd_create_multi(const rd_config *cfg, int n_streams, rd_demod **out);
 int rd_demod_blocks(rd_demod *h, const uint8_t *iq, size_t nbytes, rd_packet *out, int cap, int *n);
+/*
+ * The same call split in two, for a receiver loop that must not wait (replaces the hop
+ * runners/rtlsdr.py:100-103 `data_queue.put(samples)` -> worker.py:34-50 `demodulate(samples)`):
+ * rd_demod_submit copies the block(s) into a pinned slot, starts the host-to-device copy on a copy stream
+ * and queues the kernels behind it on the compute stream, then returns; rd_demod_fetch waits (polling) for
+ * the OLDEST submitted block and returns its packets exactly as rd_demod_block / rd_demod_blocks would.
+ * Two blocks may be in flight (RD_ERR_STATE on a third submit): block i+1's copy overlaps block i's
+ * kernels.  count: 2 * block_size * n_streams bytes, or block_size complex128 samples (single stream).
+ * The state mirrors below need a quiet handle (everything fetched).
+ */
+int rd_demod_submit(rd_demod *h, const void *samples, size_t count, int is_complex);
+int rd_demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n);
+int rd_demod_inflight(rd_demod *h);
+/*
+ * The packets of the block returned last, again: a call that ended in RD_ERR_CAPACITY has consumed its
+ * block (the reference's list is unbounded, py:190-246: up to block_size + 1 positions per call are legal),
+ * *n told how many there are - grow the array and fetch them here.  Nothing is lost.
+ */
+int rd_demod_refetch(rd_demod *h, rd_packet *out, int cap, int *n);
 /* discriminated (py:134) of one stream of a multi-stream handle */
 int rd_copy_discriminated_stream(rd_demod *h, int stream, double *out, size_t n);
 /* Lazily materialised mirrors of the reference's state arrays after the last call:

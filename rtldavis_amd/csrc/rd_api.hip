@@ -640,28 +640,40 @@ extern "C" int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t
 // ------------------------------------------------------------------------------------------
 // streaming demodulator (py:128-253)
 // ------------------------------------------------------------------------------------------
+// One block in flight: pinned input, its device staging copy, pinned counters and mapped records.
+struct rd_slot {
+    uint8_t *h_in = nullptr;         // pinned: NS x 2B bytes (or B complex128)
+    uint8_t *d_in = nullptr;         // device staging: the H2D copy lands here on the copy stream
+    uint32_t *h_cnt = nullptr;       // pinned
+    rd_packet *h_recs = nullptr;     // pinned + mapped, rec_cap entries: written by the slice kernel
+    rd_packet *d_recs_map = nullptr; // device address of h_recs
+    hipEvent_t e_in = nullptr, e_done = nullptr;
+};
+
 struct rd_demod {
     rd_config cfg;
     rd_devcfg dc;
     bool dev_ready = false;
     bool cplx_mode = false;  // switched on by the first complex128 block, until reset
-    long seen = 0;           // blocks demodulated since reset
+    long seen = 0;           // blocks submitted since reset
     int NS = 1;              // independent streams fed in lock step (rd_create_multi)
     size_t ring_stride = 0;  // bytes between the streams' rings
     // per stream, byte ring: [hdr 32 B][prev 2B][cur 2B]; complex ring (NS == 1 only):
     // [hdr 16][prev B][cur B] complex128
     uint8_t *d_ring = nullptr;
     double *d_cring = nullptr;
-    uint8_t *d_stage = nullptr;  // staging for byte input while in complex mode
     uint32_t *d_blockbits = nullptr, *d_win[2] = {nullptr, nullptr}, *d_fix = nullptr, *d_cnt = nullptr;
     int cur_win = 0;
     rd_match *d_matches = nullptr;
     double *d_tmp = nullptr;  // 2*(B+1) doubles for the state mirrors
     double *h_tmp = nullptr;        // pinned mirror of d_tmp (state accessors)
-    uint8_t *h_in = nullptr;        // pinned staging of one input block
-    uint32_t *h_cnt = nullptr;      // pinned
-    rd_packet *h_recs = nullptr;    // pinned + mapped, rec_cap entries: written by the slice kernel
-    rd_packet *d_recs_map = nullptr; // device address of h_recs
+    // Two slots: block i+1's host-to-device copy (copy stream) runs beside block i's kernels (compute
+    // stream).  rd_demod_block = submit + fetch of one block; rd_demod_submit / rd_demod_fetch expose the
+    // pipeline (runners/rtlsdr.py:100-103 -> worker.py:34-58 without the pickled-queue hop).
+    rd_slot slot[2];
+    int head = 0, nflight = 0;      // oldest block in flight, blocks in flight (0..2)
+    hipStream_t st = nullptr, st_copy = nullptr;
+    std::vector<rd_packet> last;    // ordered, deduplicated records of the last fetched block
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     bool fast_ok = false;
 };
@@ -695,7 +707,6 @@ static int demod_alloc(rd_demod *h) {
     const size_t ring_bytes = NS * h->ring_stride + RD_INPUT_PAD;
     HIPCHK(hipMalloc(&h->d_ring, ring_bytes));
     HIPCHK(hipMemset(h->d_ring, 127, ring_bytes));
-    HIPCHK(hipMalloc(&h->d_stage, 2 * B));
     h->fix_cap = (uint32_t)(NS * ((B + 31) / 32));  // every run of a block
     h->match_cap = (uint32_t)(NS * (B + 1));        // every position of every window: cannot overflow
     h->rec_cap = h->match_cap;
@@ -708,11 +719,21 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
     HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&h->h_in, std::max(16 * B, NS * 2 * B), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->h_tmp, 2 * (2 * B + 2) * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocMapped));
-    HIPCHK(hipHostGetDevicePointer((void **)&h->d_recs_map, h->h_recs, 0));
+    const size_t in_bytes = std::max(16 * B, NS * 2 * B);
+    for (int i = 0; i < 2; i++) {
+        rd_slot &sl = h->slot[i];
+        HIPCHK(hipHostMalloc((void **)&sl.h_in, in_bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&sl.d_in, in_bytes));
+        HIPCHK(hipHostMalloc((void **)&sl.h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&sl.h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&sl.d_recs_map, sl.h_recs, 0));
+        HIPCHK(hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.e_done, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
+    HIPCHK(hipDeviceSynchronize());  // the memsets above ran on the null stream
     h->dev_ready = true;
     return RD_OK;
 }
@@ -720,22 +741,49 @@ static int demod_alloc(rd_demod *h) {
 extern "C" void rd_destroy(rd_demod *h) {
     if (!h) return;
     if (h->dev_ready && g_hip_pid == getpid()) {
-        hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_stage); hipFree(h->d_blockbits);
+        if (h->st) hipStreamSynchronize(h->st);
+        if (h->st_copy) hipStreamSynchronize(h->st_copy);
+        hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_tmp);
-        hipHostFree(h->h_in); hipHostFree(h->h_cnt); hipHostFree(h->h_recs); hipHostFree(h->h_tmp);
+        hipHostFree(h->h_tmp);
+        for (int i = 0; i < 2; i++) {
+            rd_slot &sl = h->slot[i];
+            hipHostFree(sl.h_in); hipFree(sl.d_in); hipHostFree(sl.h_cnt); hipHostFree(sl.h_recs);
+            if (sl.e_in) hipEventDestroy(sl.e_in);
+            if (sl.e_done) hipEventDestroy(sl.e_done);
+        }
+        if (h->st) hipStreamDestroy(h->st);
+        if (h->st_copy) hipStreamDestroy(h->st_copy);
     }
     delete h;
 }
 
+// every block in flight has been fetched (state accessors and reset need a quiet handle)
+static int demod_quiet(const rd_demod *h) {
+    if (h->nflight) return fail(RD_ERR_STATE, "%d block(s) in flight: rd_demod_fetch them first", h->nflight);
+    return RD_OK;
+}
+
 extern "C" int rd_reset(rd_demod *h) {
     if (!h) return fail(RD_ERR_ARG, "null handle");
+    if (h->dev_ready) {
+        // blocks still in flight are dropped: wait for them, then clear
+        for (int i = 0; i < h->nflight; i++) {
+            int rc = wait_event(h->slot[(h->head + i) & 1].e_done);
+            if (rc) return rc;
+        }
+        const size_t L = (size_t)h->dc.L;
+        for (int i = 0; i < 2; i++)
+            HIPCHK(hipMemsetAsync(h->d_win[i], 0, (size_t)h->NS * ((L + 31) / 32) * 4, h->st));
+        int rc = wait_stream(h->st);
+        if (rc) return rc;
+    }
+    h->nflight = 0;
+    h->head = 0;
     h->seen = 0;
     h->cplx_mode = false;
-    if (h->dev_ready) {
-        const size_t L = (size_t)h->dc.L;
-        for (int i = 0; i < 2; i++) HIPCHK(hipMemset(h->d_win[i], 0, (size_t)h->NS * ((L + 31) / 32) * 4));
-    }
+    h->last.clear();
     return RD_OK;
 }
 
@@ -773,25 +821,34 @@ static rd_cplx_layout demod_clayout(const rd_demod *h, long seen_before) {
 static int demod_enter_cplx(rd_demod *h) {
     const size_t B = (size_t)h->dc.B;
     if (!h->d_cring) HIPCHK(hipMalloc(&h->d_cring, 2 * (16 + 2 * B) * sizeof(double)));
-    rd_launch_lut(h->d_ring, h->d_cring, 16 + 2 * B, nullptr);
+    rd_launch_lut(h->d_ring, h->d_cring, 16 + 2 * B, h->st);
     HIPCHK(hipGetLastError());
     h->cplx_mode = true;
     return RD_OK;
 }
 
-// One block per stream (uint8: NS x 2B bytes, stream-major; complex128: single stream only).
-static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_packet *out, int cap, int *n) {
+// Queue one block per stream (uint8: NS x 2B bytes, stream-major; complex128: single stream only): the
+// copy to the device on the copy stream, everything else behind it on the compute stream.  Returns at
+// once; at most two blocks may be in flight.
+static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
     const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L, NS = (size_t)h->NS;
     const size_t bw = (B + 31) / 32, lw = (L + 31) / 32;
     int rc = demod_alloc(h);
     if (rc) return rc;
-    hipStream_t st = nullptr;
+    if (h->nflight >= 2) return fail(RD_ERR_STATE, "two blocks in flight: rd_demod_fetch one first");
+    rd_slot &sl = h->slot[(h->head + h->nflight) & 1];
+    hipStream_t st = h->st;
+    const size_t nbytes = is_complex ? 2 * B * sizeof(double) : NS * 2 * B;
+    memcpy(sl.h_in, samples, nbytes);
+    HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, nbytes, hipMemcpyHostToDevice, h->st_copy));
+    HIPCHK(hipEventRecord(sl.e_in, h->st_copy));
+    HIPCHK(hipStreamWaitEvent(st, sl.e_in, 0));
     if (is_complex && !h->cplx_mode) {
         rc = demod_enter_cplx(h);
         if (rc) return rc;
     }
     const long seen_before = h->seen;
-    // roll the raw rings left by one block (py:140,154): hdr <- tail of prev, prev <- cur
+    // roll the raw rings left by one block (py:140,154): hdr <- tail of prev, prev <- cur, cur <- the new block
     if (!h->cplx_mode) {
         uint8_t *r = h->d_ring;
         const size_t rs = h->ring_stride;
@@ -799,8 +856,7 @@ static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_pac
             HIPCHK(hipMemcpy2DAsync(r, rs, r + 2 * B, rs, 32, NS, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpy2DAsync(r + 32, rs, r + 32 + 2 * B, rs, 2 * B, NS, hipMemcpyDeviceToDevice, st));
         }
-        memcpy(h->h_in, samples, NS * 2 * B);
-        HIPCHK(hipMemcpy2DAsync(r + 32 + 2 * B, rs, h->h_in, 2 * B, 2 * B, NS, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(r + 32 + 2 * B, rs, sl.d_in, 2 * B, 2 * B, NS, hipMemcpyDeviceToDevice, st));
     } else {
         double *r = h->d_cring;
         if (seen_before > 0) {
@@ -808,12 +864,9 @@ static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_pac
             HIPCHK(hipMemcpyAsync(r + 32, r + 32 + 2 * B, 2 * B * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         if (is_complex) {
-            memcpy(h->h_in, samples, 2 * B * sizeof(double));
-            HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, h->h_in, 2 * B * sizeof(double), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(r + 32 + 2 * B, sl.d_in, 2 * B * sizeof(double), hipMemcpyDeviceToDevice, st));
         } else {
-            memcpy(h->h_in, samples, 2 * B);
-            HIPCHK(hipMemcpyAsync(h->d_stage, h->h_in, 2 * B, hipMemcpyHostToDevice, st));
-            rd_launch_lut(h->d_stage, r + 32 + 2 * B, B, st);
+            rd_launch_lut(sl.d_in, r + 32 + 2 * B, B, st);
         }
     }
     HIPCHK(hipMemsetAsync(h->d_cnt, 0, RD_CNT_SLOTS * 4, st));
@@ -832,28 +885,77 @@ static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_pac
     rd_launch_search(h->d_win[nw], lw, h->NS, (long)L, 0, (long)B, h->dc, h->d_matches, h->match_cap, h->d_cnt, st);
     if (!h->cplx_mode)
         rd_launch_slice(demod_layout(h, seen_before), h->d_win[nw], lw, (long)L, h->dc, h->d_matches, h->match_cap, 0,
-                        0, (int)seen_before, nullptr, h->d_recs_map, h->d_cnt, st);
+                        0, (int)seen_before, nullptr, sl.d_recs_map, h->d_cnt, st);
     else
         rd_launch_cplx_slice(demod_clayout(h, seen_before), h->d_win[nw], (long)L, h->dc, h->d_matches, h->match_cap,
-                             (int)seen_before, nullptr, h->d_recs_map, h->d_cnt, st);
+                             (int)seen_before, nullptr, sl.d_recs_map, h->d_cnt, st);
     HIPCHK(hipGetLastError());
     // The counters come back with the block; the few records of a block are written by the slice
     // kernel straight into pinned host memory (no copy to wait for; for the thousands of records of
-    // a batch run the same was measured slower than a device buffer + one copy).  Polling wait.
-    HIPCHK(hipMemcpyAsync(h->h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
-    rc = wait_stream(st);
-    if (rc) return rc;
+    // a batch run the same was measured slower than a device buffer + one copy).
+    HIPCHK(hipMemcpyAsync(sl.h_cnt, h->d_cnt, RD_CNT_SLOTS * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(sl.e_done, st));
     h->seen = seen_before + 1;
-    const uint32_t nrec = std::min(h->h_cnt[RD_CNT_MATCH], h->match_cap);  // one record per match (no call overlap here)
-    std::vector<rd_packet> recs;
-    order_and_dedupe(h->h_recs, nrec, h->dc.S, recs);
-    *n = (int)recs.size();
-    if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
-    if (!recs.empty()) {
+    h->nflight++;
+    return RD_OK;
+}
+
+static int demod_give(rd_demod *h, rd_packet *out, int cap, int *n) {
+    *n = (int)h->last.size();
+    if ((int)h->last.size() > cap)
+        return fail(RD_ERR_CAPACITY, "need room for %zu packets (rd_demod_refetch returns them)", h->last.size());
+    if (!h->last.empty()) {
         if (!out) return fail(RD_ERR_ARG, "null out");
-        memcpy(out, recs.data(), recs.size() * sizeof(rd_packet));
+        memcpy(out, h->last.data(), h->last.size() * sizeof(rd_packet));
     }
     return RD_OK;
+}
+
+// Wait (polling) for the oldest block in flight and return its packets in the reference's order.
+static int demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {
+    if (h->nflight == 0) return fail(RD_ERR_STATE, "no block in flight");
+    rd_slot &sl = h->slot[h->head];
+    int rc = wait_event(sl.e_done);
+    if (rc) return rc;
+    h->head ^= 1;
+    h->nflight--;
+    const uint32_t nrec = std::min(sl.h_cnt[RD_CNT_MATCH], h->match_cap);  // one record per match (no call overlap here)
+    order_and_dedupe(sl.h_recs, nrec, h->dc.S, h->last);
+    return demod_give(h, out, cap, n);
+}
+
+extern "C" int rd_demod_submit(rd_demod *h, const void *samples, size_t count, int is_complex) {
+    if (!h || !samples) return fail(RD_ERR_ARG, "null argument");
+    const size_t B = (size_t)h->dc.B, NS = (size_t)h->NS;
+    // py:32-36 / py:145-149
+    if (is_complex) {
+        if (NS != 1) return fail(RD_ERR_STATE, "complex input needs a single-stream handle");
+        if (count != B) return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu, expected %zu", count, B);
+    } else {
+        if (count != NS * 2 * B) return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu, expected %zu", count, NS * 2 * B);
+        if (h->cplx_mode && NS != 1) return fail(RD_ERR_STATE, "handle is in complex mode: reset() first");
+    }
+    return demod_submit(h, samples, is_complex);
+}
+
+extern "C" int rd_demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {
+    if (!h || !n) return fail(RD_ERR_ARG, "null argument");
+    return demod_fetch(h, out, cap, n);
+}
+
+extern "C" int rd_demod_refetch(rd_demod *h, rd_packet *out, int cap, int *n) {
+    if (!h || !n) return fail(RD_ERR_ARG, "null argument");
+    return demod_give(h, out, cap, n);
+}
+
+extern "C" int rd_demod_inflight(rd_demod *h) { return h ? h->nflight : 0; }
+
+static int demod_blocks(rd_demod *h, const void *samples, int is_complex, rd_packet *out, int cap, int *n) {
+    int rc = demod_quiet(h);
+    if (rc) return rc;
+    rc = demod_submit(h, samples, is_complex);
+    if (rc) return rc;
+    return demod_fetch(h, out, cap, n);
 }
 
 extern "C" int rd_demod_block(rd_demod *h, const void *samples, size_t count, int is_complex, rd_packet *out, int cap,
@@ -889,11 +991,13 @@ extern "C" int rd_copy_discriminated_stream(rd_demod *h, int stream, double *out
         memset(out, 0, n * sizeof(double));
         return RD_OK;
     }
+    int rc = demod_quiet(h);
+    if (rc) return rc;
     // discriminated = d over [-B, B) relative to the newest block (py:156,162)
-    if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), stream, -(long)B, 2 * (long)B, h->d_tmp, nullptr);
-    else rd_launch_cplx_disc(demod_clayout(h, h->seen - 1), -(long)B, 2 * (long)B, h->d_tmp, nullptr);
+    if (!h->cplx_mode) rd_launch_disc(demod_layout(h, h->seen - 1), stream, -(long)B, 2 * (long)B, h->d_tmp, h->st);
+    else rd_launch_cplx_disc(demod_clayout(h, h->seen - 1), -(long)B, 2 * (long)B, h->d_tmp, h->st);
     HIPCHK(hipGetLastError());
-    int rc = copy_d2h(h->h_tmp, h->d_tmp, n * sizeof(double), nullptr);  // pinned: no staging, polling wait
+    rc = copy_d2h(h->h_tmp, h->d_tmp, n * sizeof(double), h->st);  // pinned: no staging, polling wait
     if (rc) return rc;
     memcpy(out, h->h_tmp, n * sizeof(double));
     return RD_OK;
@@ -907,11 +1011,13 @@ extern "C" int rd_copy_filtered(rd_demod *h, double *out_interleaved, size_t n_c
         memset(out_interleaved, 0, 2 * n_complex * sizeof(double));
         return RD_OK;
     }
+    int rc = demod_quiet(h);
+    if (rc) return rc;
     // filtered[j] = f[j-1] relative to the newest block (py:155,161)
-    if (!h->cplx_mode) rd_launch_filtered(demod_layout(h, h->seen - 1), 0, -1, (long)B + 1, h->d_tmp, nullptr);
-    else rd_launch_cplx_filtered(demod_clayout(h, h->seen - 1), -1, (long)B + 1, h->d_tmp, nullptr);
+    if (!h->cplx_mode) rd_launch_filtered(demod_layout(h, h->seen - 1), 0, -1, (long)B + 1, h->d_tmp, h->st);
+    else rd_launch_cplx_filtered(demod_clayout(h, h->seen - 1), -1, (long)B + 1, h->d_tmp, h->st);
     HIPCHK(hipGetLastError());
-    int rc = copy_d2h(h->h_tmp, h->d_tmp, 2 * n_complex * sizeof(double), nullptr);
+    rc = copy_d2h(h->h_tmp, h->d_tmp, 2 * n_complex * sizeof(double), h->st);
     if (rc) return rc;
     memcpy(out_interleaved, h->h_tmp, 2 * n_complex * sizeof(double));
     return RD_OK;
@@ -927,7 +1033,9 @@ extern "C" int rd_copy_quantized(rd_demod *h, uint8_t *out, size_t n) {
     }
     std::vector<uint32_t> words((L + 31) / 32);
     if (words.size() * 4 > 2 * (2 * (size_t)h->dc.B + 2) * sizeof(double)) return fail(RD_ERR_ARG, "window too large");
-    int rc = copy_d2h(h->h_tmp, h->d_win[h->cur_win], words.size() * 4, nullptr);
+    int rc = demod_quiet(h);
+    if (rc) return rc;
+    rc = copy_d2h(h->h_tmp, h->d_win[h->cur_win], words.size() * 4, h->st);
     if (rc) return rc;
     memcpy(words.data(), h->h_tmp, words.size() * 4);
     for (size_t t = 0; t < L; t++) out[t] = (uint8_t)((words[t >> 5] >> (t & 31)) & 1u);  // unpack only

@@ -388,6 +388,9 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         // issue order; the previous iteration's word store and list flush are older or harmless)
         if (NBUF == 2 && nx1.tile < total_tiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the short stretch from "data has landed" to "next loads issued" runs at raised priority: a wave whose
+        // tile arrived should not queue behind three other waves' vector work before it can ask for the next
+        if (!(stflags & 4)) __builtin_amdgcn_s_setprio(3);  // (RD_K1_STFLAGS & 4 switches it off: A/B)
         rd_u2v D[9];
         const uint32_t boff = buf * RD_MF_IMG_PAD;
         rd_mf_read_window(img_addr + boff + prv, img_addr + boff + own, D);
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         const rd_mf_pos nx2 = rd_mf_next(nx1, chunk, tiles_per_stream, jump, jq, jr);
         const rd_mf_pos fetch = NBUF == 2 ? nx2 : nx1;
         if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane);
+        if (!(stflags & 4)) __builtin_amdgcn_s_setprio(0);
 
         uint32_t word = 0, fbytes = 0;
         if (DBG == 2 || DBG == 6) {

@@ -162,7 +162,8 @@ class Demodulator:
             self._pid = os.getpid()
         return self._h
 
-    def demodulate(self, input_data: np.ndarray) -> List[Packet]:
+    def _check_block(self, input_data: np.ndarray):
+        """Size checks of dsp.py:32-36,145-149 and a contiguous buffer of the right type."""
         bs = self.cfg.block_size
         if np.iscomplexobj(input_data):
             if input_data.size != bs:
@@ -176,15 +177,41 @@ class Demodulator:
                 raise ValueError("Incompatible array sizes")
             buf = np.ascontiguousarray(input_data, dtype=np.uint8)
             count, is_c = buf.size, 0
-        n = C.c_int(0)
-        L = _lib.lib()
-        rc = L.rd_demod_block(self._handle(), buf.ctypes.data, count, is_c, self._recs, self._cap, C.byref(n))
+        return buf, count, is_c
+
+    def _take(self, rc: int, n: "C.c_int") -> List[Packet]:
+        """Packets of a finished call.  The reference's list is unbounded (dsp.py:190-246): when the
+        record array was too small the block has still been consumed and its packets are kept by the
+        handle - grow the array and fetch them again."""
         if rc == _lib.RD_ERR_CAPACITY:
-            # the block is already consumed; results stay on the device only until the next
-            # call, so this cannot be retried - size the list for the worst case up front
-            raise BufferError(_lib.last_error())
+            self._cap = max(2 * self._cap, n.value)
+            self._recs = (_lib.RdPacket * self._cap)()
+            rc = _lib.lib().rd_demod_refetch(self._handle(), self._recs, self._cap, C.byref(n))
         _lib.check(rc)
         return _packets_from(self._recs, n.value)
+
+    def demodulate(self, input_data: np.ndarray) -> List[Packet]:
+        buf, count, is_c = self._check_block(input_data)
+        n = C.c_int(0)
+        rc = _lib.lib().rd_demod_block(self._handle(), buf.ctypes.data, count, is_c, self._recs, self._cap, C.byref(n))
+        return self._take(rc, n)
+
+    # --- the same call in two halves (SURVEY section 8f-4; worker.py:34-58 without the wait) ---
+    def submit(self, input_data: np.ndarray) -> None:
+        """Queue one block: host-to-device copy and kernels run asynchronously; at most two blocks
+        may be in flight.  ``fetch()`` returns their packets in submission order."""
+        buf, count, is_c = self._check_block(input_data)
+        _lib.check(_lib.lib().rd_demod_submit(self._handle(), buf.ctypes.data, count, is_c))
+
+    def fetch(self) -> List[Packet]:
+        """Packets of the oldest block in flight (waits for it)."""
+        n = C.c_int(0)
+        rc = _lib.lib().rd_demod_fetch(self._handle(), self._recs, self._cap, C.byref(n))
+        return self._take(rc, n)
+
+    @property
+    def inflight(self) -> int:
+        return int(_lib.lib().rd_demod_inflight(self._handle()))
 
     def reset(self) -> None:
         _lib.check(_lib.lib().rd_reset(self._handle()))
@@ -232,16 +259,18 @@ class MultiDemodulator:
         except Exception:
             pass
 
-    def demodulate(self, blocks: np.ndarray) -> List[List[Packet]]:
-        """blocks: uint8 [n_streams, 2*block_size].  Returns one ``List[Packet]`` per stream."""
+    def _check_blocks(self, blocks: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(blocks, dtype=np.uint8)
         if a.size != self.n_streams * 2 * self.cfg.block_size:
             logger.error(f"Incompatible array sizes: blocks.size={a.size}")
             raise ValueError("Incompatible array sizes")
-        n = C.c_int(0)
-        rc = _lib.lib().rd_demod_blocks(self._h, a.ctypes.data, a.size, self._recs, self._cap, C.byref(n))
-        if rc == _lib.RD_ERR_CAPACITY:
-            raise BufferError(_lib.last_error())
+        return a
+
+    def _take(self, rc: int, n: "C.c_int") -> List[List[Packet]]:
+        if rc == _lib.RD_ERR_CAPACITY:  # nothing is lost: the handle keeps the block's packets (dsp.py:190-246)
+            self._cap = max(2 * self._cap, n.value)
+            self._recs = (_lib.RdPacket * self._cap)()
+            rc = _lib.lib().rd_demod_refetch(self._h, self._recs, self._cap, C.byref(n))
         _lib.check(rc)
         out: List[List[Packet]] = [[] for _ in range(self.n_streams)]
         for i in range(n.value):
@@ -249,6 +278,28 @@ class MultiDemodulator:
             data = np.frombuffer(bytes(r.data[: r.nbytes]), dtype=np.uint8)
             out[r.stream].append(Packet(int(r.index), data, float(r.rssi), float(r.snr)))
         return out
+
+    def demodulate(self, blocks: np.ndarray) -> List[List[Packet]]:
+        """blocks: uint8 [n_streams, 2*block_size].  Returns one ``List[Packet]`` per stream."""
+        a = self._check_blocks(blocks)
+        n = C.c_int(0)
+        rc = _lib.lib().rd_demod_blocks(self._h, a.ctypes.data, a.size, self._recs, self._cap, C.byref(n))
+        return self._take(rc, n)
+
+    def submit(self, blocks: np.ndarray) -> None:
+        """Queue one block per stream (asynchronous copy + kernels; at most two in flight)."""
+        a = self._check_blocks(blocks)
+        _lib.check(_lib.lib().rd_demod_submit(self._h, a.ctypes.data, a.size, 0))
+
+    def fetch(self) -> List[List[Packet]]:
+        """Packets of the oldest submitted set of blocks, per stream."""
+        n = C.c_int(0)
+        rc = _lib.lib().rd_demod_fetch(self._h, self._recs, self._cap, C.byref(n))
+        return self._take(rc, n)
+
+    @property
+    def inflight(self) -> int:
+        return int(_lib.lib().rd_demod_inflight(self._h))
 
     def reset(self) -> None:
         _lib.check(_lib.lib().rd_reset(self._h))

@@ -1,0 +1,154 @@
+"""DSP worker loops on the GPU demodulator.
+
+Counterpart of the reference's ``worker.worker_main`` (src/rtldavis/worker.py:10-58): blocks arrive on
+a ``multiprocessing.Queue`` (``None`` stops the loop, a 1 s poll keeps it interruptible), each block
+is demodulated and parsed, messages go to ``result_queue``; an exception in the DSP step is logged
+and the block dropped (worker.py:56-58).  Two things differ, both invisible to the caller:
+
+* the demodulator call is split into ``submit`` / ``fetch`` (rd_demod_submit / rd_demod_fetch), so
+  the host-to-device copy of block i+1 runs beside the kernels of block i and the loop parses block
+  i while block i+1 is on the GPU - the pickled-queue hop of runners/rtlsdr.py:100-103 stays the
+  caller's, the wait inside ``demodulate`` is gone;
+* ``multi_worker_main`` drains several ``data_queue``s (one per dongle / hop channel) into ONE
+  ``MultiDemodulator`` launch per round.
+
+The protocol layer is not rebuilt here: ``parser_factory`` supplies the reference's own
+``protocol.Parser`` (with ``rtldavis.dsp`` swapped for ``rtldavis_amd.dsp``) or any
+object with ``.cfg``, ``.demodulator`` and ``.parse(packets)``.
+"""
+from __future__ import annotations
+
+import logging
+import queue
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import dsp
+
+
+def _get(q, timeout: float):
+    """data_queue.get with the reference's semantics: (block, False), or (None, True) on the stop
+    sentinel, or (None, False) when nothing arrived in time (worker.py:35-46)."""
+    try:
+        samples = q.get(timeout=timeout)
+    except queue.Empty:
+        return None, False
+    if samples is None:
+        return None, True
+    return samples, False
+
+
+def worker_main(data_queue, result_queue, parser_factory: Callable[[], object],
+                log_level: int = logging.INFO, poll_s: float = 1.0) -> None:
+    """worker.worker_main (worker.py:10-58) with the demodulator pipelined one block deep.
+
+    ``parser_factory()`` must return the parser (reference: ``protocol.Parser(symbol_length=...,
+    station_id=...)``, worker.py:29); its ``demodulator`` has to be an ``rtldavis_amd.dsp.Demodulator``.
+    """
+    logging.basicConfig(level=log_level, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    logger = logging.getLogger("rtldavis.worker")
+    logger.info("DSP worker process started")
+    try:
+        p = parser_factory()
+    except Exception as e:  # worker.py:30-32
+        logger.exception(f"Failed to initialize worker: {e}")
+        return
+    dem = p.demodulator
+    pending = False  # a block is on the GPU, its packets not yet fetched
+
+    def finish() -> None:
+        nonlocal pending
+        try:
+            packets = dem.fetch()
+            # parse() reads demodulator.discriminated for the block just fetched (protocol.py:304-311):
+            # the handle is quiet here, the next block is submitted only afterwards
+            for msg in p.parse(packets):
+                result_queue.put(msg)
+        except Exception as e:  # worker.py:56-58: log, drop the block, go on
+            logger.error(f"Error in DSP loop: {e}")
+        pending = False
+
+    while True:
+        try:
+            samples, stop = _get(data_queue, 0.0 if pending else poll_s)
+        except KeyboardInterrupt:
+            break
+        if samples is None and not stop:
+            if pending:
+                finish()  # nothing new to overlap with: deliver what is in flight
+            continue
+        if pending:
+            finish()
+        if stop:
+            logger.info("Worker received stop signal")
+            break
+        try:
+            dem.submit(samples)
+            pending = True
+        except Exception as e:
+            logger.error(f"Error in DSP loop: {e}")
+    if pending:
+        finish()
+
+
+class _StreamView:
+    """What ``Parser.parse`` reads from its demodulator (protocol.py:304-311), for one stream of a
+    ``MultiDemodulator``."""
+
+    def __init__(self, multi: dsp.MultiDemodulator, stream: int) -> None:
+        self._multi, self._stream = multi, stream
+        self.cfg = multi.cfg
+
+    @property
+    def discriminated(self) -> np.ndarray:
+        return self._multi.discriminated(self._stream)
+
+
+def multi_worker_main(data_queues: Sequence, result_queue, parser_factory: Callable[[int], object],
+                      log_level: int = logging.INFO, poll_s: float = 1.0) -> None:
+    """Several receivers, one GPU launch per round: every ``data_queue`` delivers one block per
+    round (lock step, like dongles clocked alike); the blocks are demodulated together by one
+    ``MultiDemodulator`` and parsed per stream; messages go to ``result_queue`` as ``(stream, msg)``.
+    A ``None`` on any queue stops the worker.  ``parser_factory(k)`` supplies stream k's parser; its
+    ``demodulator`` attribute is replaced by a view onto stream k of the shared demodulator.
+    """
+    logging.basicConfig(level=log_level, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    logger = logging.getLogger("rtldavis.worker")
+    n = len(data_queues)
+    try:
+        parsers = [parser_factory(k) for k in range(n)]
+        multi = dsp.MultiDemodulator(parsers[0].cfg, n)
+        for k, p in enumerate(parsers):
+            p.demodulator = _StreamView(multi, k)
+    except Exception as e:
+        logger.exception(f"Failed to initialize worker: {e}")
+        return
+    logger.info(f"DSP worker started for {n} receivers")
+    bs2 = 2 * multi.cfg.block_size
+    while True:
+        blocks: List[Optional[np.ndarray]] = []
+        stop = False
+        for q in data_queues:
+            while True:
+                try:
+                    samples, stop = _get(q, poll_s)
+                except KeyboardInterrupt:
+                    stop = True
+                if samples is not None or stop:
+                    break
+            if stop:
+                break
+            blocks.append(samples)
+        if stop:
+            logger.info("Worker received stop signal")
+            break
+        try:
+            arr = np.stack([np.ascontiguousarray(b, dtype=np.uint8).reshape(bs2) for b in blocks])
+            per_stream = multi.demodulate(arr)
+            for k, p in enumerate(parsers):
+                for msg in p.parse(per_stream[k]):
+                    result_queue.put((k, msg))
+        except Exception as e:
+            logger.error(f"Error in DSP loop: {e}")
+            continue
