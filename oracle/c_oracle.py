@@ -23,9 +23,39 @@ class OraclePkt(C.Structure):
 
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "dsp_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    newest = os.path.join(HERE, "_build", "liboracle_v4.so")
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(newest) or \
+            os.path.getmtime(newest) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", HERE])
     return LIB_PATH
+
+
+def best_isa_level() -> int:
+    """Highest x86-64 micro-architecture level (2, 3 or 4) this host's /proc/cpuinfo flags cover."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            flags = set()
+            for line in fh:
+                if line.startswith("flags"):
+                    flags = set(line.split(":", 1)[1].split())
+                    break
+    except OSError:
+        return 2
+    v3 = {"avx", "avx2", "bmi1", "bmi2", "f16c", "fma", "movbe", "xsave", "abm"}  # abm = lzcnt
+    v4 = {"avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"}
+    if v3 <= flags:
+        return 4 if v4 <= flags else 3
+    return 2
+
+
+def use_isa_level(level: int) -> int:
+    """Switch the loaded library to the build for `level` (2..4, clamped to what the host runs);
+    returns the level in use.  The tests stay on the default v2 build."""
+    global _lib, LIB_PATH
+    level = max(2, min(int(level), best_isa_level()))
+    LIB_PATH = os.path.join(HERE, "_build", "liboracle.so" if level == 2 else f"liboracle_v{level}.so")
+    _lib = None
+    return level
 
 
 _lib = None

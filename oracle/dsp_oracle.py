@@ -128,6 +128,18 @@ def quantize(d: np.ndarray) -> np.ndarray:
     return np.signbit(np.asarray(d, dtype=np.float64)).astype(np.uint8)
 
 
+def quantize_per_sample(d: np.ndarray) -> np.ndarray:
+    """quantize as the reference executes it (src/rtldavis/dsp.py:93-98): one Python-level step per
+    sample that takes the top bit of the IEEE-754 pattern.  Same result as ``quantize``; it exists so
+    that the CPU baseline's per-block leg has the reference's cost structure (this loop is 86 % of the
+    reference's run time)."""
+    import struct
+    out = np.empty(len(d), dtype=np.uint8)
+    for i, v in enumerate(d):
+        out[i] = struct.unpack("<Q", struct.pack("<d", v))[0] >> 63
+    return out
+
+
 def search(quantized: np.ndarray, cfg: OracleConfig) -> List[int]:
     """Demodulator._search (src/rtldavis/dsp.py:171-188): phase-major order."""
     out: List[int] = []
@@ -183,8 +195,9 @@ def rssi_snr(filtered: np.ndarray, q_idx: int, cfg: OracleConfig) -> Tuple[float
 class OracleDemodulator:
     """Mirror of dsp.Demodulator (src/rtldavis/dsp.py:128-253)."""
 
-    def __init__(self, cfg: OracleConfig):
+    def __init__(self, cfg: OracleConfig, per_sample_quantize: bool = False):
         self.cfg = cfg
+        self._quantize = quantize_per_sample if per_sample_quantize else quantize
         self.reset()
 
     def reset(self) -> None:
@@ -214,7 +227,7 @@ class OracleDemodulator:
         self.iq[9:] = rotate_fs4(block)
         self.filtered[1:] = fir9(self.iq, B)
         self.discriminated[B:] = discriminate(self.filtered)
-        self.quantized[c.buffer_length - B:] = quantize(self.discriminated[B:])
+        self.quantized[c.buffer_length - B:] = self._quantize(self.discriminated[B:])
         return self._slice(search(self.quantized, c))
 
     def _slice(self, indices: Sequence[int]) -> List[OraclePacket]:

@@ -240,6 +240,8 @@ struct rd_batch {
     long n_samples;      // per stream
     size_t bits_stride;  // words per stream
     bool dev_ready = false, fast_ok = false, ran = false, timing = false, timing_detail = false;
+    bool run_timing = false, run_detail = false;  // the timing mode latched by the run in flight
+    int device = -1;      // the device the buffers live on (set by the first device call)
     bool fetched = false;  // batch_finish has seen the last run complete
     uint8_t *d_iq = nullptr;
     size_t iq_bytes = 0;
@@ -304,10 +306,18 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
 
 static uint32_t *batch_cnt(const rd_batch *b) { return b->d_cnt + (size_t)b->cnt_set * RD_CNT_SLOTS; }
 
+// A handle is tied to the device that was current when its buffers were allocated; every entry point
+// makes that device current for the calling thread first (handles may be used from several threads).
+static int use_device(int device) {
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    return RD_OK;
+}
+
 static int batch_alloc(rd_batch *b) {
-    if (b->dev_ready) return RD_OK;
+    if (b->dev_ready) return use_device(b->device);
     int rc = ensure_device();
     if (rc) return rc;
+    HIPCHK(hipGetDevice(&b->device));
     const uint64_t runs = (uint64_t)b->n_streams * b->bits_stride;
     b->iq_bytes = (size_t)b->n_streams * b->n_samples * 2;
     // guard-band list: one entry per flagged 32-sample run (~1.5 % of the runs on noise)
@@ -336,6 +346,7 @@ static int batch_alloc(rd_batch *b) {
 extern "C" void rd_batch_destroy(rd_batch *b) {
     if (!b) return;
     if (b->dev_ready && g_hip_pid == getpid()) {
+        if (b->device >= 0) hipSetDevice(b->device);
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs);
         hipFree(b->d_parsed);
@@ -369,34 +380,37 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
 }
 
 // search + slice part of a run (re-issued on list overflow)
-static void batch_search_slice(rd_batch *b, hipStream_t st) {
+static int batch_search_slice(rd_batch *b, hipStream_t st) {
     const rd_layout lay = batch_layout(b);
     const long B = b->dc.B, L = b->dc.L;
     rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
                      b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
-    if (b->timing && b->timing_detail) hipEventRecord(b->ev[3], st);
+    if (b->run_timing && b->run_detail) HIPCHK(hipEventRecord(b->ev[3], st));
     // the run's last kernel carries the end-of-run event itself when nothing follows it
-    hipEvent_t last = b->timing ? b->ev[4] : b->kdone;
+    hipEvent_t last = b->run_timing ? b->ev[4] : b->kdone;
     const bool last_on_slice = !b->parse;
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
                     b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr);
     if (b->parse) {
-        if (!b->d_parsed) hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed));
-        if (b->d_parsed) rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
+        if (!b->d_parsed) HIPCHK(hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed)));
+        rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
     }
     // results come back with the run: counters plus as many records as the last run produced
     // (+25 %); rd_batch_results fetches the remainder if this run produced more.
     // The copies run on their own stream so that another batch's kernels queued on `st` need
     // not wait for them.  Every event recorded between two kernels idles the GPU for a few
     // microseconds, so a timed run's end-of-run event doubles as the copy stream's trigger.
-    if (!last_on_slice) hipEventRecord(last, st);
-    hipStreamWaitEvent(b->copy_stream, last, 0);
-    hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost, b->copy_stream);
+    if (!last_on_slice) HIPCHK(hipEventRecord(last, st));
+    HIPCHK(hipStreamWaitEvent(b->copy_stream, last, 0));
+    HIPCHK(hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          b->copy_stream));
     const uint32_t spec = std::min(b->match_cap, b->spec_recs);
     if (spec)
-        hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
-                       b->copy_stream);
-    hipEventRecord(b->done, b->copy_stream);
+        HIPCHK(hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
+                              b->copy_stream));
+    HIPCHK(hipEventRecord(b->done, b->copy_stream));
+    HIPCHK(hipGetLastError());
+    return RD_OK;
 }
 
 extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
@@ -413,6 +427,8 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;
     uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * RD_CNT_SLOTS;
+    b->run_timing = b->timing;  // set_timing between run() and results() does not touch the run in flight
+    b->run_detail = b->timing_detail;
     if (b->timing) {
         if (b->evs.size() < 5 * (b->ev_runs + 1)) {
             const size_t old = b->evs.size();
@@ -432,8 +448,8 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     }
     rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
-    batch_search_slice(b, st);
-    HIPCHK(hipGetLastError());
+    rc = batch_search_slice(b, st);
+    if (rc) return rc;
     b->ran = true;
     return RD_OK;
 }
@@ -478,7 +494,8 @@ static int batch_finish(rd_batch *b) {
         }
         const uint32_t zero[4] = {0, 0, 0, 0};  // matches, boundary records, (unused), parsed
         HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
-        batch_search_slice(b, st);
+        int rc2 = batch_search_slice(b, st);
+        if (rc2) return rc2;
     }
     return fail(RD_ERR_DEVICE, "result lists kept overflowing");
 }
@@ -494,12 +511,15 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     const uint32_t nprim = std::min(b->h_cnt[RD_CNT_MATCH], b->match_cap);
     const uint32_t nextra = std::min(b->h_cnt[RD_CNT_REC], b->match_cap);
     const uint32_t have = std::min(b->match_cap, b->spec_recs);
+    // Late copies go to the copy stream: it has already waited for this run's last kernel, whereas the
+    // launch stream may hold the NEXT batch's run by now (two resident batches alternate in bench.py) and a
+    // copy queued there would wait for it.
     if (nprim > have) {  // more records than were copied back with the run: fetch the rest
-        rc = copy_d2h(b->h_recs_pin + have, b->d_recs + have, (size_t)(nprim - have) * sizeof(rd_packet), b->stream);
+        rc = copy_d2h(b->h_recs_pin + have, b->d_recs + have, (size_t)(nprim - have) * sizeof(rd_packet), b->copy_stream);
         if (rc) return rc;
     }
-    if (nextra) {
-        rc = copy_d2h(b->h_recs_pin + nprim, b->d_recs + b->match_cap, (size_t)nextra * sizeof(rd_packet), b->stream);
+    if (nextra) {  // second records of block-boundary positions (q == B in one call, q == 0 in the next)
+        rc = copy_d2h(b->h_recs_pin + nprim, b->d_recs + b->match_cap, (size_t)nextra * sizeof(rd_packet), b->copy_stream);
         if (rc) return rc;
     }
     const uint32_t nrec = nprim + nextra;
@@ -657,6 +677,7 @@ struct rd_demod {
     bool cplx_mode = false;  // switched on by the first complex128 block, until reset
     long seen = 0;           // blocks submitted since reset
     int NS = 1;              // independent streams fed in lock step (rd_create_multi)
+    int device = -1;         // the device the buffers live on
     size_t ring_stride = 0;  // bytes between the streams' rings
     // per stream, byte ring: [hdr 32 B][prev 2B][cur 2B]; complex ring (NS == 1 only):
     // [hdr 16][prev B][cur B] complex128
@@ -700,9 +721,10 @@ extern "C" int rd_create(const rd_config *cfg, rd_demod **out) { return rd_creat
 static size_t ring_cur_off(const rd_demod *h) { return 32 + 2 * (size_t)h->dc.B; }
 
 static int demod_alloc(rd_demod *h) {
-    if (h->dev_ready) return RD_OK;
+    if (h->dev_ready) return use_device(h->device);
     int rc = ensure_device();
     if (rc) return rc;
+    HIPCHK(hipGetDevice(&h->device));
     const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L, NS = (size_t)h->NS;
     const size_t ring_bytes = NS * h->ring_stride + RD_INPUT_PAD;
     HIPCHK(hipMalloc(&h->d_ring, ring_bytes));
@@ -741,6 +763,7 @@ static int demod_alloc(rd_demod *h) {
 extern "C" void rd_destroy(rd_demod *h) {
     if (!h) return;
     if (h->dev_ready && g_hip_pid == getpid()) {
+        if (h->device >= 0) hipSetDevice(h->device);
         if (h->st) hipStreamSynchronize(h->st);
         if (h->st_copy) hipStreamSynchronize(h->st_copy);
         hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_blockbits);
@@ -1132,6 +1155,7 @@ extern "C" int rd_quantize(const double *in, uint8_t *out, size_t n) {
 extern "C" int rd_search(const rd_config *cfg, const uint8_t *quantized, size_t n, int32_t *indices, int cap,
                          int *count) {
     if (!count) return fail(RD_ERR_ARG, "null count");
+    if (!cfg) return fail(RD_ERR_ARG, "null config");
     rd_devcfg dc;
     rd_config c2 = *cfg;
     if (c2.block_size < 32) c2.block_size = 32;  // block size is irrelevant to a bare search

@@ -44,6 +44,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <unistd.h>
 
 #include <hip/hip_runtime.h>
 
@@ -79,6 +80,8 @@ struct rd_chan {
     uint8_t *d_wide = nullptr;     // resident capture, 2 bytes per sample
     size_t wide_cap = 0, wide_n = 0;
     bool dev_ready = false;
+    int device = -1;               // the device the buffers live on
+    pid_t pid = 0;                 // the process that allocated them
 };
 
 // x mod m for integer-valued 0 <= x < 2^53, 1 <= m < 2^26 (exact: one fma, one correction step)
@@ -313,14 +316,21 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
 
 extern "C" void rd_chan_destroy(rd_chan *h) {
     if (!h) return;
-    if (h->dev_ready) { hipFree(h->d_amat); hipFree(h->d_dc); hipFree(h->d_shifts); hipFree(h->d_wide); }
+    // device memory belongs to the process that allocated it: a forked copy only drops its host state
+    if (h->dev_ready && h->pid == getpid()) {
+        if (h->device >= 0) hipSetDevice(h->device);
+        hipFree(h->d_amat); hipFree(h->d_dc); hipFree(h->d_shifts); hipFree(h->d_wide);
+    }
     delete h;
 }
 
 static int chan_alloc(rd_chan *h, size_t n_wide) {
     int rc = rd_ensure_device_public();
     if (rc) return rc;
+    if (h->dev_ready && h->device >= 0) CHK(hipSetDevice(h->device));
     if (!h->dev_ready) {
+        CHK(hipGetDevice(&h->device));
+        h->pid = getpid();
         CHK(hipMalloc(&h->d_amat, h->h_amat.size() * sizeof(uint16_t)));
         CHK(hipMemcpy(h->d_amat, h->h_amat.data(), h->h_amat.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         CHK(hipMalloc(&h->d_dc, h->h_dc.size() * sizeof(float)));
