@@ -8,7 +8,8 @@ One process per GPU (launched by torch.distributed.run for N > 1).  Streams are
 independent, so each rank demodulates its own shard and no collective touches the data
 path (weak scaling: 4096 streams per GPU, BASELINE.json configs[3] / configs[4]).  A
 step = one full pass over the rank's resident batch: rd_batch_run (all kernels) followed by
-rd_batch_results (device->host copy of the packets, per-call ordering and dedupe).  Two
+rd_batch_results (device->host copy of the packets, per-call ordering and dedupe).
+Two
 resident copies of the batch are demodulated alternately so that the host part of step i
 (results) overlaps the GPU part of step i+1 - the double-buffered shape of a receiver that
 demodulates one capture while the next one arrives; every step still does all of its work
@@ -31,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before anything initialises HIP (torch does): small device->host copies on the SDMA engines, not on a
+# blit kernel that competes with the demod kernel for the CUs (see rtldavis_amd/__init__.py)
+os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 UNIQUE = 64            # unique synthetic streams, tiled to fill the batch
@@ -48,6 +52,9 @@ def parse_args():
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of back-to-back steps after the timed region (reported separately; 0 = off)")
     ap.add_argument("--two-streams", action="store_true", help="one HIP stream per resident batch")
+    ap.add_argument("--resident", type=int, default=2,
+                    help="resident copies of the batch demodulated round-robin (>= 2): runs queued ahead of the host; "
+                         "3 and 4 measured no better than 2 (profiles/r02_resident_sweep.txt)")
     ap.add_argument("--stage-times", action="store_true", help="time every kernel stage (adds events)")
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "
@@ -238,33 +245,41 @@ def main():
         np.stack([synth.synth_stream(s, n_samples=max(n_samples, 3 * 8192 + 2000))[: 2 * n_samples] for s in seeds])
     reps = (n_streams + nu - 1) // nu
     host = np.tile(uniq, (reps, 1))[:n_streams]
-    bds = [batch.BatchDemodulator(cfg, n_streams, n_blocks) for _ in range(2)]
+    bds = [batch.BatchDemodulator(cfg, n_streams, n_blocks) for _ in range(max(2, args.resident))]
     bd = bds[0]
     t_h2d = time.perf_counter()
     bd.upload(host)
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t_h2d
-    bds[1].upload(host)
+    for x in bds[1:]:
+        x.upload(host)
     in_bytes = host.nbytes
     del host
 
     # --two-streams gives each resident batch its own HIP stream; measured: no gain, the demod
     # kernel's persistent grid leaves no room for another batch's kernels to run beside it
-    tstreams = [torch.cuda.Stream() for _ in bds] if args.two_streams else [torch.cuda.current_stream()] * 2
+    tstreams = [torch.cuda.Stream() for _ in bds] if args.two_streams else [torch.cuda.current_stream()] * len(bds)
     streams = [t.cuda_stream for t in tstreams]
     for x in bds:
         x.set_timing(2 if args.stage_times else 1)  # 1: demod kernel + whole run (an event between two
         # kernels idles the GPU for ~6 us, so the per-stage split is opt-in and comes from rocprofv3)
 
+    R = len(bds)
+
     def run_steps(k):
-        """k full steps; step i = bds[i%2].run + its results(); results(i) overlaps run(i+1)."""
+        """k full steps; step i = bds[i % R].run + its results().  R resident copies of the batch are
+        demodulated round-robin with R - 1 runs queued ahead, so that the host part of step i (results:
+        wait, D2H of the packets, per-call ordering and dedupe, ~0.4 ms) overlaps the GPU part of the
+        following steps and the GPU never waits for a launch."""
         recs = None
-        bds[0].run(streams[0])
-        for i in range(1, k):
-            bds[i % 2].run(streams[i % 2])
-            recs = bds[(i - 1) % 2].results()  # D2H of the packets + per-call ordering
-        recs = bds[(k - 1) % 2].results()
-        return recs, bds[(k - 1) % 2]
+        for i in range(min(R - 1, k)):
+            bds[i % R].run(streams[i % R])
+        for i in range(k):
+            nxt = i + R - 1
+            if nxt < k:
+                bds[nxt % R].run(streams[nxt % R])
+            recs = bds[i % R].results()
+        return recs, bds[(k - 1) % R]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -335,21 +350,23 @@ def main():
 
     # HBM traffic of the dominant kernel: measured with PMC counters in a separate rocprofv3 run
     # (tools/pmc_traffic.sh) and committed under profiles/; valid for the default workload only
-    # (tools/profile_round.sh) and committed under profiles/ together with the sha256 of the library it
-    # was measured on: a file that belongs to another build of the kernels is refused.
+    # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel sources
+    # it was measured on: a file that belongs to other kernels is refused.
     traffic, traffic_note = None, None
     try:
-        import hashlib
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import profile_collect
         with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
             tj = json.load(fh)
-        with open(_lib.LIB_PATH, "rb") as fh:
-            so_sha = hashlib.sha256(fh.read()).hexdigest()
         w = tj["workload"]
-        if tj.get("library_sha256") != so_sha:
-            traffic_note = "profiles/r02_traffic.json was measured on another build of librtldavis_hip.so: not used"
-        elif (w["streams"], w["blocks"], w["block_size"]) == (n_streams, n_blocks, cfg.block_size):
+        if tj.get("sources_sha256") != profile_collect.sources_sha256():
+            traffic_note = ("profiles/r02_traffic.json was measured on other kernel sources (stamp "
+                            f"{str(tj.get('sources_sha256'))[:12]}, commit {tj.get('commit')}): not used; "
+                            "regenerate with tools/profile_round.sh")
+        elif (w["streams"], w["blocks"], w["block_size"]) == (n_streams, n_blocks, cfg.block_size) \
+                and not os.environ.get("RD_K1_IMPL"):
             traffic = int(tj["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError, ImportError):
         pass
 
     if rank == 0:

@@ -4,9 +4,10 @@ runs in its own subprocess; all share one GPU box and are interleaved round-robi
 usage: k1_ab.py [--key demod_ms] 'NAME=ENV1=V1,ENV2=V2' ...   (NAME alone = defaults)"""
 import json, os, subprocess, sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.environ["RD_REPO_ROOT"])
 import numpy as np
 from rtldavis_amd import batch, dsp, synth
 cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 8192)
@@ -35,8 +36,8 @@ def main():
     res = {n: [] for n, _ in variants}
     for rnd in range(3):
         for name, env in variants:
-            e = dict(os.environ); e.update(env)
-            out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True, cwd=os.getcwd())
+            e = dict(os.environ); e.update(env); e["RD_REPO_ROOT"] = ROOT
+            out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True, cwd=ROOT)
             try:
                 t = json.loads(out.stdout.strip().splitlines()[-1])
                 res[name].append(t if key == "all" else t[key])
@@ -44,6 +45,8 @@ def main():
                 print(name, "FAILED", out.stderr[-400:])
     if key == "all":
         for name, v in res.items():
+            if not v:
+                continue
             print(f"{name:24s} " + "  ".join(f"{k[:-3]} {min(x[k] for x in v):.4f}" for k in v[0] if k != "runs"))
         return
     for name, v in res.items():

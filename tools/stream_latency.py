@@ -1,25 +1,63 @@
-"""Per-call latency of the streaming Demodulator (one 8192-sample block = 30.5 ms of air time)."""
+"""Latency and throughput of the streaming handle (one 8192-sample block = 30.5 ms of air time):
+the synchronous call (rd_demod_block), the same call split in two with two blocks in flight
+(rd_demod_submit / rd_demod_fetch: block i+1's host-to-device copy beside block i's kernels), and
+sixteen receivers in lock step through one handle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from rtldavis_amd import dsp, synth
 cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", 8192)
+B = cfg.block_size
 raw = synth.synth_stream(0)
+blocks = [raw[2 * B * b: 2 * B * (b + 1)] for b in range(33)]
 dem = dsp.Demodulator(cfg)
 ts = []
 npk = 0
-for rep in range(3):
+for rep in range(6):
     dem.reset()
-    for b in range(33):
-        blk = raw[2 * 8192 * b: 2 * 8192 * (b + 1)]
+    for blk in blocks:
         t0 = time.perf_counter()
         pk = dem.demodulate(blk)
         ts.append(time.perf_counter() - t0)
         npk += len(pk)
 ts = np.array(ts[5:]) * 1e3
-print(f"demodulate(): median {np.median(ts):.3f} ms, p99 {np.percentile(ts, 99):.3f} ms, max {ts.max():.3f} ms over {ts.size} calls; {npk} packets")
+print(f"demodulate(): median {np.median(ts):.3f} ms, p99 {np.percentile(ts, 99):.3f} ms, max {ts.max():.3f} ms over {ts.size} calls; "
+      f"{1e3 / np.mean(ts):.0f} blocks/s = {1e3 / np.mean(ts) * B / 1e6:.1f} MS/s; {npk} packets")
+# pipelined: two blocks in flight
+npk2 = 0
+t0 = time.perf_counter()
+reps = 20
+for rep in range(reps):
+    dem.reset()
+    dem.submit(blocks[0])
+    for blk in blocks[1:]:
+        dem.submit(blk)
+        npk2 += len(dem.fetch())
+    npk2 += len(dem.fetch())
+dt = time.perf_counter() - t0
+print(f"submit()/fetch(), two blocks in flight: {reps * 33 / dt:.0f} blocks/s = {reps * 33 * B / dt / 1e6:.1f} MS/s "
+      f"({1e3 * dt / (reps * 33):.3f} ms per block); {npk2} packets ({npk2 // reps} per stream)")
+# sixteen receivers in lock step
+NS = 16
+raws = synth.synth_streams(range(NS))
+md = dsp.MultiDemodulator(cfg, NS)
+for mode in ("demodulate", "submit/fetch"):
+    md.reset()
+    t0 = time.perf_counter()
+    n = 0
+    if mode == "demodulate":
+        for b in range(33):
+            n += sum(len(x) for x in md.demodulate(raws[:, 2 * B * b: 2 * B * (b + 1)]))
+    else:
+        md.submit(raws[:, : 2 * B])
+        for b in range(1, 33):
+            md.submit(raws[:, 2 * B * b: 2 * B * (b + 1)])
+            n += sum(len(x) for x in md.fetch())
+        n += sum(len(x) for x in md.fetch())
+    dt = time.perf_counter() - t0
+    print(f"{NS} receivers, {mode}: {33 / dt:.0f} rounds/s = {33 * NS * B / dt / 1e6:.1f} MS/s ({1e3 * dt / 33:.3f} ms per round), {n} packets")
 t0 = time.perf_counter(); d = dem.discriminated; t1 = time.perf_counter()
 print(f".discriminated materialisation {1e3*(t1-t0):.3f} ms")
-for _ in range(3):
+for _ in range(2):
     t0 = time.perf_counter(); d = dem.discriminated; t1 = time.perf_counter(); f = dem.filtered; t2 = time.perf_counter(); q = dem.quantized; t3 = time.perf_counter()
     print(f"again: discriminated {1e3*(t1-t0):.3f} ms, filtered {1e3*(t2-t1):.3f} ms, quantized {1e3*(t3-t2):.3f} ms")
