@@ -41,6 +41,10 @@
 // + the offset constant (four copies); a multiple of 32 so that XOR 16 toggles between the two carry slots
 #define RD_MF_XB_BYTES (3 * 1024 + 32 + 32)
 #define RD_MF_PEND 32
+// tiles whose words are stored together (a multiple of 4 that divides the default chunk)
+#ifndef RD_MF_STAGE_TILES
+#define RD_MF_STAGE_TILES 4
+#endif
 
 typedef _Float16 rd_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rd_h2 __attribute__((ext_vector_type(2)));
@@ -255,12 +259,15 @@ __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count
 // Store the staged words: four tiles as one 16-byte store per lane, fewer tile by tile.
 __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t nst, uint32_t *base, int lane,
                                                    uint32_t stflags) {
-    if (nst == 4) {
-        const rd_u4v v = rd_lds_read16u(stage_addr + 16 * lane);
-        // non-temporal: the words are read next by another kernel, never again by this one (0.3-1.3 % faster;
-        // RD_K1_STFLAGS & 1 switches to plain stores for A/B runs)
-        if (!(stflags & 1)) __builtin_nontemporal_store(v, (rd_u4v *)(base + 4 * lane));
-        else *(rd_u4v *)(base + 4 * lane) = v;
+    if (nst == RD_MF_STAGE_TILES) {
+#pragma unroll
+        for (int j = 0; j < RD_MF_STAGE_TILES / 4; j++) {
+            const rd_u4v v = rd_lds_read16u(stage_addr + 16 * (lane + 64 * j));
+            // non-temporal: the words are read next by another kernel, never again by this one (0.3-1.3 % faster;
+            // RD_K1_STFLAGS & 1 switches to plain stores for A/B runs)
+            if (!(stflags & 1)) __builtin_nontemporal_store(v, (rd_u4v *)(base + 4 * (lane + 64 * j)));
+            else *(rd_u4v *)(base + 4 * (lane + 64 * j)) = v;
+        }
     } else {
         for (uint32_t q = 0; q < nst; q++) base[64 * q + lane] = rd_lds_read4(stage_addr + 256 * q + 4 * lane);
     }
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
     // packed words of up to four consecutive tiles of a stream, stored together: one 16-byte store per lane
     // (1 KiB contiguous per wave) instead of four dword stores (round 1: a dword store per tile cost 20 % of
     // the read bandwidth, profiles/r01_ubench_read_bw.txt)
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[RD_MF_WAVES][4][64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[RD_MF_WAVES][RD_MF_STAGE_TILES][64];
     constexpr bool LOADS = DBG != 1 && DBG != 4 && DBG != 5;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         rd_mf_read_window(img_addr + boff + prv, img_addr + boff + own, D);
         // the window is in registers: this buffer takes the tile after next
         // stores of finished tiles go out here, before the loads (they share vmcnt, in issue order)
-        if (nst == 4 || (nst && st_flush)) {
+        if (nst == RD_MF_STAGE_TILES || (nst && st_flush)) {
             rd_mf_store_staged(stage_addr, nst, st_base, lane, stflags);
             nst = 0;
         }
