@@ -228,16 +228,23 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     }
 }
 
+// cache policy of the tile loads (the builtin's aux operand): 0 default, 2 = nt.  The input is streamed
+// once and never re-read: nt loads-only 0.330 ms (6.7 TB/s) against 0.358, loads + stores 0.427 against 0.462,
+// whole kernel 0.496 against 0.509, and the search kernel behind it finds more of the bits in cache.
+#ifndef RD_MF_LOAD_AUX
+#define RD_MF_LOAD_AUX 2
+#endif
+
 __device__ __forceinline__ void rd_mf_issue(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *img, int lane) {
     const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
     const int perm = 8 * (lane & 7) + (lane >> 3);
     const __attribute__((address_space(1))) void *g0 = (const __attribute__((address_space(1))) void *)(src + perm * 16);
     // the instruction offset advances the global and the LDS address alike; the LDS base makes up
     // the difference between the 1024-byte source groups and the 1152-byte image groups
-    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16 + 128), 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16 + 256), 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16 + 384), 16, 3072, 0);
+    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16), 16, 0, RD_MF_LOAD_AUX);
+    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16 + 128), 16, 1024, RD_MF_LOAD_AUX);
+    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16 + 256), 16, 2048, RD_MF_LOAD_AUX);
+    __builtin_amdgcn_global_load_lds(g0, (__attribute__((address_space(3))) void *)(img + 16 + 384), 16, 3072, RD_MF_LOAD_AUX);
     // the 16 bytes before the tile (previous tile, or the caller's history).  With zero history there
     // is nothing to read: the first run of the stream is re-evaluated exactly anyway.
     const bool has_halo = (ti > 0) || lay.hist_mode;
