@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--two-streams", action="store_true", help="one HIP stream per resident batch")
     ap.add_argument("--resident", type=int, default=2,
                     help="resident copies of the batch demodulated round-robin (>= 2): runs queued ahead of the host; "
-                         "3 and 4 measured no better than 2 (profiles/r02_resident_sweep.txt)")
+                         "3 and 4 measured no better than 2 (profiles/r02_readback_sdma.txt)")
     ap.add_argument("--stage-times", action="store_true", help="time every kernel stage (adds events)")
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "

@@ -41,8 +41,8 @@ def main():
             try:
                 t = json.loads(out.stdout.strip().splitlines()[-1])
                 res[name].append(t if key == "all" else t[key])
-            except Exception:
-                print(name, "FAILED", out.stderr[-400:])
+            except Exception as ex:
+                print(name, "FAILED", repr(ex), out.stderr[-400:])
     if key == "all":
         for name, v in res.items():
             if not v:

@@ -1,0 +1,20 @@
+# LDS counters of the fused demod kernel under the bench load (own run: counters only).
+# usage: pmc_lds.sh [tag]
+cd /tmp && export TMPDIR=/tmp
+TAG=${1:-lds}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+rm -rf $OUT
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-verify > $OUT.log 2>&1
+python3 - <<PY
+import csv, glob, collections, os
+root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_$TAG"
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("kernel,counter,mean_value,n")
+for k, d in agg.items():
+    if "demod" not in k: continue
+    for c, v in sorted(d.items()):
+        print(f"{k},{c},{sum(v)/len(v):.1f},{len(v)}")
+PY
