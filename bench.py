@@ -45,6 +45,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle", type=float, default=0.05,
+                    help="seconds of untimed steps in front of the W warmup steps (reported as `settle`): the chip "
+                         "needs ~30 ms of continuous load after the idle upload phase before its clocks settle - "
+                         "a 20-step region started cold runs the demod kernel at 0.57 ms, warm at 0.52 "
+                         "(profiles/r02_clock_settle.txt); 0 switches it off")
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=33, help="8192-sample blocks per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -287,6 +292,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The upload leaves the compute units idle for 0.1-0.3 s and the chip clocks down; it takes ~30 ms of load to
+    # come back (profiles/r02_clock_settle.txt).  A step is 0.65 ms, so W = 5 warmup steps end long before that and
+    # a short timed region would measure the ramp, not the path.  The settle phase is untimed, disclosed in the
+    # output line, and the same steps as everything else; the K timed steps follow the W warmup steps unchanged.
+    settle_steps, settle_s = 0, 0.0
+    if args.settle > 0:
+        ts = time.perf_counter()
+        while time.perf_counter() - ts < args.settle:
+            run_steps(4 * R)
+            settle_steps += 4 * R
+        settle_s = time.perf_counter() - ts
     if args.warmup:
         run_steps(args.warmup)
     sync_all()
@@ -396,6 +412,8 @@ def main():
             "packets_per_step": len(recs), "verified_vs_reference_fixtures": verified,
             "h2d_s": round(t_h2d, 3),
         }
+        out["settle"] = {"seconds": round(settle_s, 3), "steps": settle_steps,
+                         "note": "untimed steps in front of the warmup (clock ramp after the idle upload phase)"}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
         if sustained:
