@@ -201,7 +201,9 @@ def wideband(args):
                      "kernel_ms": round(1e3 * dt_c, 4),
                      "note": "useful flops (8 x taps per output); the kernel issues 3x as many bf16 MACs (split taps) "
                              "on 128 rows for 102; kernel_ms is wall time per launch, back to back"},
-        "packets_recovered": f"{ok} of {len(info)}", "real_time_factor": round(n_out / CZ.OUT_RATE / dt, 1)}), flush=True)
+        "packets_recovered": f"{ok} of {len(info)}", "real_time_factor": round(n_out / CZ.OUT_RATE / dt, 1),
+        "parity": "unpinned: rtldavis has no channelizer to compare with; checked against this repo's float64 model "
+                  "(<= 1 LSB) and by recovering the injected packets through the pinned demodulator"}), flush=True)
 
 
 def main():
