@@ -701,3 +701,37 @@ def test_sharded_demodulation_with_the_real_batch_demodulator(dsp, batchmod, gol
         lo, hi = shard_range(len(seeds), 4, r)
         parts += [(lo + s, c, p) for (s, c, p) in (demod(load(lo, hi)) if hi > lo else [])]
     assert parts == want
+
+
+def test_degenerate_patterns_match_the_reference(dsp, batchmod):
+    """Constant, period-2 and period-4 byte patterns against the REAL reference's output
+    (tests/golden/degenerate_patterns.json, tools/gen_golden_degenerate.py): the inputs where the discriminator is
+    closest to a tie (|d| down to 1.5e-5 on a -Fs/4 tone), streaming handle and batch path."""
+    g = load_json("degenerate_patterns.json")
+    B = g["block_size"]
+    names = sorted(g["patterns"])
+    blocks = []
+    for name in names:
+        fx = g["patterns"][name]
+        flat = np.array([v for pair in fx["period"] for v in pair], dtype=np.uint8)
+        blk = np.tile(flat, 2 * B // flat.size)
+        blocks.append(blk)
+        dem = dsp.Demodulator(prod_cfg(dsp))
+        for c, want in enumerate(fx["calls"]):
+            pk = dem.demodulate(blk)
+            q = np.asarray(dem.quantized).astype(np.uint8)
+            assert q.size == want["n"]
+            assert int(q.sum()) == want["ones"], f"{name} call {c}"
+            assert sha(np.packbits(q, bitorder="little")) == want["quantized_packed_sha256"], f"{name} call {c}"
+            assert [[int(p.index), bytes(p.data).hex()] for p in pk] == want["packets"], f"{name} call {c}"
+    # batch path: every pattern as one stream of g["blocks"] identical blocks; the last call's window is the
+    # stream's last 2B bits
+    nb = g["blocks"]
+    raw = np.stack([np.tile(b, nb) for b in blocks])
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(names), nb)
+    res = bd.demodulate(raw)
+    for i, name in enumerate(names):
+        want = g["patterns"][name]["calls"]
+        bits = np.unpackbits(bd.bits(i).view(np.uint8), bitorder="little")[: nb * B]
+        assert sha(np.packbits(bits[(nb - 2) * B:], bitorder="little")) == want[-1]["quantized_packed_sha256"], name
+        assert [[[int(p.index), bytes(p.data).hex()] for p in call] for call in res[i]] == [w["packets"] for w in want], name

@@ -178,3 +178,26 @@ def test_crc_and_bitswap_kats():
     for hx in synth.OTA_PACKETS:
         d = bytes(O.swap_bit_order(b) for b in bytes.fromhex(hx))
         assert O.crc16_ccitt(d[2:]) == 0
+
+
+def _degenerate_block(period, B):
+    flat = np.array([v for pair in period for v in pair], dtype=np.uint8)
+    return np.tile(flat, 2 * B // flat.size)
+
+
+def test_degenerate_patterns_pin_the_oracle():
+    """Constant, period-2 and period-4 byte patterns (tools/gen_golden_degenerate.py, real reference): the inputs
+    where the discriminator is closest to a tie (|d| down to 1.5e-5 on a -Fs/4 tone)."""
+    g = load_json("degenerate_patterns.json")
+    B = g["block_size"]
+    assert B == PROD.block_size
+    for name, fx in g["patterns"].items():
+        dem = O.OracleDemodulator(PROD)
+        blk = _degenerate_block(fx["period"], B)
+        for c, want in enumerate(fx["calls"]):
+            pk = dem.demodulate(blk)
+            q = np.asarray(dem.quantized).astype(np.uint8)
+            assert q.size == want["n"]
+            assert int(q.sum()) == want["ones"], f"{name} call {c}"
+            assert sha(np.packbits(q, bitorder="little")) == want["quantized_packed_sha256"], f"{name} call {c}"
+            assert [[int(p.index), bytes(p.data).hex()] for p in pk] == want["packets"], f"{name} call {c}"
