@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import math
 import os
 from dataclasses import dataclass
 from typing import List
@@ -127,7 +128,12 @@ def _packets_from(recs, n: int) -> List[Packet]:
     for i in range(n):
         r = recs[i]
         data = np.frombuffer(bytes(r.data[: r.nbytes]), dtype=np.uint8)  # read-only, like dsp.py:241
-        out.append(Packet(index=int(r.index), data=data, rssi=float(r.rssi), snr=float(r.snr)))
+        snr = float(r.snr)
+        if snr == -math.inf:
+            # signal_power == 0 over a non-silent noise estimate: the reference's math.log10(0) raises out of
+            # demodulate() at this packet (dsp.py:231-236); the device reports the same condition as -inf
+            raise ValueError("math domain error")
+        out.append(Packet(index=int(r.index), data=data, rssi=float(r.rssi), snr=snr))
     return out
 
 

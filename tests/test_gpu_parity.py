@@ -735,3 +735,13 @@ def test_degenerate_patterns_match_the_reference(dsp, batchmod):
         bits = np.unpackbits(bd.bits(i).view(np.uint8), bitorder="little")[: nb * B]
         assert sha(np.packbits(bits[(nb - 2) * B:], bitorder="little")) == want[-1]["quantized_packed_sha256"], name
         assert [[[int(p.index), bytes(p.data).hex()] for p in call] for call in res[i]] == [w["packets"] for w in want], name
+
+
+def test_zero_signal_power_raises_like_reference(dsp):
+    """dsp.py:231-236: signal_power == 0 over a non-zero noise estimate ends in math.log10(0), a ValueError out of
+    demodulate().  Reachable with complex zeros and an all-zero preamble (checked against the real reference:
+    'math domain error' on the first call)."""
+    cfg = dsp.PacketConfig(19200, 4, 4, 8, "0000", 512)
+    dem = dsp.Demodulator(cfg)
+    with pytest.raises(ValueError, match="math domain error"):
+        dem.demodulate(np.zeros(512, dtype=np.complex128))

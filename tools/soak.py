@@ -63,13 +63,19 @@ def soak(n_cases, seed, verbose=True):
                 assert ok, (tag, i, a, b)
             nrec += len(got)
         # streaming handle on stream 0 (skip when a call exceeds its 64-packet limit)
+        # A call in which some packet has signal_power == 0 (a preamble of zeros matching inside the zero start-up
+        # state) ends in the reference's math.log10(0): ValueError out of demodulate(), the call's packets are
+        # lost, the state has advanced (dsp.py:231-236).  The oracle reports that packet with snr = -inf.
         dem = dsp.Demodulator(cfg)
-        try:
-            calls = [dem.demodulate(raw[0][2 * B * b: 2 * B * (b + 1)]) for b in range(nb)]
-            got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(calls) for p in ps]
-            assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[0]], (tag, "streaming")
-        except BufferError:
-            pass
+        raising = {p.call for p in want[0] if np.isinf(p.snr) and p.snr < 0}
+        for b in range(nb):
+            exp = [(p.index, bytes(p.data).hex()) for p in want[0] if p.call == b]
+            try:
+                got = [(p.index, bytes(p.data).hex()) for p in dem.demodulate(raw[0][2 * B * b: 2 * B * (b + 1)])]
+                assert b not in raising, (tag, "streaming: the reference raises here", b)
+                assert got == exp, (tag, "streaming", b)
+            except ValueError as e:
+                assert "math domain error" in str(e) and b in raising, (tag, "streaming", b, str(e))
         if verbose and case % 20 == 0:
             print(f"case {case}: ok ({nrec} packets so far, {time.time() - t0:.0f} s)", flush=True)
     if verbose:
