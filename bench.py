@@ -192,14 +192,14 @@ def wideband(args):
         "metric": "wideband complex MSamples/s channelized into 51 hop channels and demodulated",
         "value": round(n_out * cz.decim / dt / 1e6, 1), "unit": "MS/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 (channelizer, fp32 accumulate) + f32 (demod)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f16 (channelizer, two tap digits, fp32 accumulate) + f32 (demod)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: 51 US hop channels from one {n_out * cz.decim / 1e6:.1f} M-sample "
                                f"uint8 IQ capture at 26.88 MS/s ({n_out / CZ.OUT_RATE:.2f} s of air), 1 MI355X",
                    "channels": cz.n_channels, "taps": int(cz.taps.size), "decimation": cz.decim},
         "roofline": {"bound": "mfma", "achieved": round(flops / dt_c / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": round(flops / dt_c / 1e12 / 2500.0, 4), "traffic": None, "kernel": "k_channelize",
                      "kernel_ms": round(1e3 * dt_c, 4),
-                     "note": "useful flops (8 x taps per output); the kernel issues 3x as many bf16 MACs (split taps) "
+                     "note": "useful flops (8 x taps per output); the kernel issues 2x as many f16 MACs (taps split into two digits) "
                              "on 128 rows for 102; kernel_ms is wall time per launch, back to back"},
         "packets_recovered": f"{ok} of {len(info)}", "real_time_factor": round(n_out / CZ.OUT_RATE / dt, 1),
         "parity": "unpinned: rtldavis has no channelizer to compare with; checked against this repo's float64 model "

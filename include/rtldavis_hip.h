@@ -212,8 +212,8 @@ int rd_search(const rd_config *cfg, const uint8_t *quantized, size_t n, int32_t 
  * of one 26.88 MS/s capture, written straight into a batch demodulator's input buffer.
  * The reference has no channelizer (it retunes one dongle per hop, runners/rtlsdr.py:51,72):
  * parity is unpinned; the definition is in rtldavis_amd/csrc/rd_channelizer.hip and restated in
- * float64 by oracle/channelizer_oracle.py.  It runs on the matrix cores (bf16 MFMA with the fp32 taps
- * split into three bf16 terms; the 8-bit samples are exact in bf16, accumulation is fp32): output
+ * float64 by oracle/channelizer_oracle.py.  It runs on the matrix cores (f16 MFMA with the taps split
+ * into two f16 digits, 2^-22 relative; the 8-bit samples are exact in f16, accumulation is fp32): output
  * bytes may differ from the float64 model by one LSB where the sum lands on a rounding boundary.
  * ------------------------------------------------------------------------------------------- */
 typedef struct rd_chan_config {

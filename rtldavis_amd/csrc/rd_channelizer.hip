@@ -14,23 +14,24 @@
 // with Fw the wideband rate, D the decimation, Fo = Fw / D; shift_c an integer number of Hz, so the
 // output phasor's phase is an exact integer remainder.
 //
-// Kernel: bf16 MFMA (v_mfma_f32_32x32x16_bf16) - the one dense contraction in this repo.  As a real
+// Kernel: f16 MFMA (v_mfma_f32_32x32x16_f16) - the one dense contraction in this repo.  As a real
 // GEMM, C[m][n] = sum_kappa A[m][kappa] B[kappa][n] with
 //   m     = 2 c + part  (part 0 = re, 1 = im of channel c; rows 2c, 2c+1 land in one lane's registers)
 //   kappa = 2 i + comp  (comp 0 = I, 1 = Q of window sample i = T-1-k, i.e. ascending in memory)
 //   A[2c][2i] = g_r, A[2c][2i+1] = -g_i, A[2c+1][2i] = g_i, A[2c+1][2i+1] = g_r    (g = g_c[T-1-i])
 //   B[2i + comp][n] = b_comp[D (t0 + n) - (T-1) + i] - 128
-// The samples are 8-bit integers: b - 128 is EXACT in bf16, and lut(b) = (b - 128 + 0.6) / 127.6, so
+// The samples are 8-bit integers: b - 128 is EXACT in f16, and lut(b) = (b - 128 + 0.6) / 127.6, so
 // z = (sum + 0.6 (1 + j) sum_k g_c[k]) / 127.6 with the second term a per-channel constant (a short
-// table for the first outputs of a capture, whose history is zero).  The fp32 taps are split into
-// three bf16 terms (hi + mid + lo reproduces 24 bits), i.e. three MFMAs per tile and K step into the
-// same fp32 accumulator: products are exact, sums are fp32 - the same error class as an fp32 chain.
+// table for the first outputs of a capture, whose history is zero).  The taps, scaled by a power of two
+// so that the largest sits just below 2^15, are split into TWO f16 terms (hi + lo: 22 bits; round 1 used
+// three bf16 terms for 24), i.e. two MFMAs per tile and K step into the same fp32 accumulator: products
+// are exact, sums are fp32, the tap error 2^-22 relative - two orders below the fp32 accumulation's.
 // 8 T flops per output: 113 GFLOP for one second of 51 channels; HBM traffic is 81 MB.
 // A workgroup = 4 waves = 128 output times x a group of 4 row blocks (64 channels); wave w owns row
 // block w and the four 32-time blocks (4 accumulator tiles).  The 127 D + T input samples are staged
-// once in LDS as bf16 pairs (I - 128, Q - 128) - 52 KiB, three workgroups per CU - so a B fragment is
+// once in LDS as f16 pairs (I - 128, Q - 128) - 52 KiB, three workgroups per CU - so a B fragment is
 // one aligned ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free).  A wave only needs its
-// own row block's A fragments (3 terms x 16 bytes per lane and K step): they come straight from L2
+// own row block's A fragments (2 terms x 16 bytes per lane and K step): they come straight from L2
 // into registers two K steps ahead; the main loop has no barrier.
 // Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.25 ms = 4000x real time.
 // On the way: fp32 VALU kernel 0.88 ms (64 TFLOP/s, bound by the CU's LDS pipe: every fma needed
@@ -38,7 +39,8 @@
 // each wave 0.55 ms (one wave per SIMD cannot hide ~25 VALU instructions per three MFMAs), A
 // through a shared LDS chunk two steps ahead instead of one 0.55 -> 0.46, samples pre-converted in
 // LDS 0.36, 128 instead of 256 output times per workgroup 0.27, A per wave from L2 without LDS or
-// barriers 0.25.
+// barriers 0.25 (three bf16 tap terms); two f16 tap terms: see DESIGN.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,21 +59,24 @@ extern int rd_ensure_device_public(void);
 #define RD_CHAN_TT (32 * RD_CHAN_TB)        // output times per workgroup
 #define RD_CHAN_RBG 4                       // row blocks (32 rows = 16 channels) per workgroup: one per wave
 #define RD_CHAN_KC 8                        // window samples per K step (taps are padded to a multiple)
-#define RD_CHAN_Q_BYTES (3 * RD_CHAN_RBG * 64 * 16)  // A bytes per K step: 3 terms x 4 row blocks x 64 lanes x 16 B
+#define RD_CHAN_TERMS 2                     // f16 digits per tap
+#define RD_CHAN_Q_BYTES (RD_CHAN_TERMS * RD_CHAN_RBG * 64 * 16)  // A bytes per K step: terms x 4 row blocks x 64 lanes x 16 B
 #ifndef RD_CHAN_NPF
 #define RD_CHAN_NPF 2                       // A chunks in flight in registers
 #endif
 #define RD_CHAN_EARLY 64                    // outputs per channel with a partial-history DC term kept in a table
 
 typedef float rd_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rd_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rd_f16x2 __attribute__((ext_vector_type(2)));
 
 struct rd_chan {
     rd_chan_config cfg;
     int n_groups = 0;              // groups of 64 channels
     int t_pad = 0;                 // taps rounded up to RD_CHAN_KC (zero taps appended)
     int n_early = 0;               // outputs whose window reaches before the capture: ceil((t_pad - 1) / D)
-    std::vector<uint16_t> h_amat;  // bf16 A operand in fragment order [group][K step][term][row block][lane][8]
+    float tap_unscale = 1.0f;      // 2^-s: the taps in h_amat are scaled by 2^s
+    std::vector<uint16_t> h_amat;  // f16 A operand in fragment order [group][K step][term][row block][lane][8]
     std::vector<float> h_dc;       // [channel][RD_CHAN_EARLY + 1][2]: 0.6 (1+j) sum of the taps a given output sees
     std::vector<int64_t> shifts;   // Hz, reduced mod out_rate
     uint16_t *d_amat = nullptr;
@@ -96,10 +101,10 @@ __device__ __forceinline__ double rd_chan_mod(double x, double m) {
 __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
                                                     const uint4 *__restrict__ amat, const float2 *__restrict__ dc,
                                                     const int64_t *shifts, int T, int D, int n_ch, int n_early,
-                                                    long out_rate, float gain, long n_out, uint8_t *out,
-                                                    size_t out_stride, int xs_bytes) {
+                                                    long out_rate, float gain, float tap_unscale, long n_out,
+                                                    uint8_t *out, size_t out_stride, int xs_bytes) {
     extern __shared__ uint8_t lds[];
-    uint8_t *xs = lds;                            // window samples 0 .. span-1 as bf16 pairs (I - 128, Q - 128)
+    uint8_t *xs = lds;                            // window samples 0 .. span-1 as f16 pairs (I - 128, Q - 128)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = row block
     const int r = lane & 31, h = lane >> 5;
@@ -140,25 +145,25 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
             for (int w = 0; w < 8; w++) {
                 const int i = i0 + w;
                 const uint32_t iq = (w4[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
-                // (I - 128, Q - 128) as a bf16 pair: exact, the upper halves of the two floats
+                // (I - 128, Q - 128) as an f16 pair: small integers, exact
                 const float fi = (float)(iq & 0xFF) - 128.0f, fq = (float)(iq >> 8) - 128.0f;
                 if (i >= 0 && i < span)
-                    ((uint32_t *)xs)[i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, fq), __builtin_bit_cast(uint32_t, fi), 0x07060302u);
+                    ((uint32_t *)xs)[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(fi, fq));
             }
         }
     }
     const uint4 *asrc = amat + (size_t)grp * (T / 8) * (RD_CHAN_Q_BYTES / 16);
     const int n_chunks = T / RD_CHAN_KC;
-    // A wave only ever needs ITS row block's A fragments (3 terms x 16 bytes per lane and K step):
+    // A wave only ever needs ITS row block's A fragments (RD_CHAN_TERMS x 16 bytes per lane and K step):
     // they come straight from L2 into registers, NPF steps ahead - no LDS, no barrier in the loop.
     constexpr int NPF = RD_CHAN_NPF;
-    const uint4 *amine = asrc + wave * 64 + lane;   // + (q * 3 + term) * RD_CHAN_RBG * 64
-    uint4 pre[NPF][3];
+    const uint4 *amine = asrc + wave * 64 + lane;   // + (q * RD_CHAN_TERMS + term) * RD_CHAN_RBG * 64
+    uint4 pre[NPF][RD_CHAN_TERMS];
 #pragma unroll
     for (int s = 0; s < NPF; s++)
 #pragma unroll
-        for (int term = 0; term < 3; term++)
-            pre[s][term] = amine[(size_t)((s < n_chunks ? s : n_chunks - 1) * 3 + term) * (RD_CHAN_RBG * 64)];
+        for (int term = 0; term < RD_CHAN_TERMS; term++)
+            pre[s][term] = amine[(size_t)((s < n_chunks ? s : n_chunks - 1) * RD_CHAN_TERMS + term) * (RD_CHAN_RBG * 64)];
     __syncthreads();  // the staged samples
 
     rd_f32x16 acc[RD_CHAN_TB];
@@ -173,21 +178,22 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
         for (int s = 0; s < NPF; s++) {
             const int q = c0 + s;
             if (q >= n_chunks) break;  // uniform
-            rd_bf16x8 a[3];
+            rd_f16x8 a[RD_CHAN_TERMS];
 #pragma unroll
-            for (int term = 0; term < 3; term++) a[term] = __builtin_bit_cast(rd_bf16x8, pre[s][term]);
+            for (int term = 0; term < RD_CHAN_TERMS; term++) a[term] = __builtin_bit_cast(rd_f16x8, pre[s][term]);
             {   // refill this slot with step q + NPF (the last steps refetch the final one: a static
                 // number of loads in flight)
                 const int qn = (q + NPF < n_chunks) ? q + NPF : n_chunks - 1;
 #pragma unroll
-                for (int term = 0; term < 3; term++) pre[s][term] = amine[(size_t)(qn * 3 + term) * (RD_CHAN_RBG * 64)];
+                for (int term = 0; term < RD_CHAN_TERMS; term++)
+                    pre[s][term] = amine[(size_t)(qn * RD_CHAN_TERMS + term) * (RD_CHAN_RBG * 64)];
             }
 #pragma unroll
             for (int tb = 0; tb < RD_CHAN_TB; tb++) {
-                const rd_bf16x8 bfrag = __builtin_bit_cast(rd_bf16x8, *(const uint4 *)(xl + 4 * (D * 32 * tb + 8 * q)));
+                const rd_f16x8 bfrag = __builtin_bit_cast(rd_f16x8, *(const uint4 *)(xl + 4 * (D * 32 * tb + 8 * q)));
 #pragma unroll
-                for (int term = 0; term < 3; term++)
-                    acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[term], bfrag, acc[tb], 0, 0, 0);
+                for (int term = 0; term < RD_CHAN_TERMS; term++)
+                    acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[term], bfrag, acc[tb], 0, 0, 0);
             }
         }
     }
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
             const int ch = 16 * (RD_CHAN_RBG * grp + wave) + (row >> 1);
             if (ch >= n_ch) continue;
             const float2 d0 = dc[(size_t)ch * (RD_CHAN_EARLY + 1) + (t < n_early ? (int)t : RD_CHAN_EARLY)];
-            const float re = acc[tb][e] + d0.x, im = acc[tb][e + 1] + d0.y;
+            const float re = __builtin_fmaf(acc[tb][e], tap_unscale, d0.x), im = __builtin_fmaf(acc[tb][e + 1], tap_unscale, d0.y);
             // phase = -2 pi frac(shift t / Fo), the remainders exact in float64
             const double fo = (double)out_rate;
             const double tm = rd_chan_mod((double)t, fo);
@@ -229,18 +235,16 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
         if (e_ != hipSuccess) return rd_fail_msg(RD_ERR_DEVICE, "%s: %s", #x, hipGetErrorString(e_));      \
     } while (0)
 
-static uint16_t bf16_rn(double v) {  // round to nearest even bf16
-    float f = (float)v;
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+static uint16_t f16_rn(double v) {  // round to nearest even f16 (|v| < 65504)
+    const _Float16 h = (_Float16)v;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
 }
-static double bf16_val(uint16_t b) {
-    uint32_t u = (uint32_t)b << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return (double)f;
+static double f16_val(uint16_t b) {
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (double)h;
 }
 
 extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, const int64_t *shift_hz, rd_chan **out) {
@@ -267,6 +271,16 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
     h->shifts.resize(cfg->n_channels);  // shift mod Fo in [0, Fo): all the output phasor needs
     for (int c = 0; c < cfg->n_channels; c++) h->shifts[c] = ((shift_hz[c] % cfg->out_rate) + cfg->out_rate) % cfg->out_rate;
     const double wide_rate = (double)cfg->out_rate * cfg->decim;
+    // every |g_c[k]| <= max |h[k]|: scale the taps by the power of two that brings that just below 2^15 (f16: 11
+    // significant bits from 2^-14 up), the kernel multiplies the sums back
+    double hmax = 0.0;
+    for (int k = 0; k < T; k++) hmax = std::max(hmax, std::fabs(taps[k]));
+    int sexp = 0;
+    if (hmax > 0.0) sexp = 14 - (int)std::ceil(std::log2(hmax));
+    if (sexp > 60) sexp = 60;
+    if (sexp < -60) sexp = -60;
+    const double tap_scale = std::ldexp(1.0, sexp);
+    h->tap_unscale = (float)std::ldexp(1.0, -sexp);
     std::vector<double> gr(t_pad), gi(t_pad);
     for (int c = 0; c < cfg->n_channels; c++) {
         for (int k = 0; k < t_pad; k++) {
@@ -299,12 +313,12 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
             for (int part = 0; part < 2; part++)
                 for (int comp = 0; comp < 2; comp++) {
                     const double a = part == 0 ? (comp == 0 ? gr[k] : -gi[k]) : (comp == 0 ? gi[k] : gr[k]);
-                    const uint16_t hi = bf16_rn(a), mid = bf16_rn(a - bf16_val(hi)),
-                                   lo = bf16_rn(a - bf16_val(hi) - bf16_val(mid));
-                    const uint16_t term[3] = {hi, mid, lo};
+                    const double as = a * tap_scale;
+                    const uint16_t hi = f16_rn(as), lo = f16_rn(as - f16_val(hi));
+                    const uint16_t term[RD_CHAN_TERMS] = {hi, lo};
                     const int lane = 32 * hh + r0 + part;
-                    for (int tm = 0; tm < 3; tm++) {
-                        const size_t at = (((((size_t)grp * n_q + q) * 3 + tm) * RD_CHAN_RBG + rb) * 64 + lane) * 8 + j0 + comp;
+                    for (int tm = 0; tm < RD_CHAN_TERMS; tm++) {
+                        const size_t at = (((((size_t)grp * n_q + q) * RD_CHAN_TERMS + tm) * RD_CHAN_RBG + rb) * 64 + lane) * 8 + j0 + comp;
                         h->h_amat[at] = term[tm];
                     }
                 }
@@ -383,7 +397,7 @@ extern "C" int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_s
     const unsigned gx = (unsigned)((n_out + RD_CHAN_TT - 1) / RD_CHAN_TT);
     hipLaunchKernelGGL(k_channelize, dim3(gx, (unsigned)h->n_groups), dim3(256), lds, (hipStream_t)hip_stream, h->d_wide,
                        (long)h->wide_n, (const uint4 *)h->d_amat, (const float2 *)h->d_dc, h->d_shifts, T, D,
-                       h->cfg.n_channels, h->n_early, (long)h->cfg.out_rate, (float)h->cfg.gain, (long)n_out,
+                       h->cfg.n_channels, h->n_early, (long)h->cfg.out_rate, (float)h->cfg.gain, h->tap_unscale, (long)n_out,
                        (uint8_t *)dst_dev, dst_stream_stride, (int)xs_bytes);
     CHK(hipGetLastError());
     return RD_OK;
