@@ -745,3 +745,23 @@ def test_zero_signal_power_raises_like_reference(dsp):
     dem = dsp.Demodulator(cfg)
     with pytest.raises(ValueError, match="math domain error"):
         dem.demodulate(np.zeros(512, dtype=np.complex128))
+
+
+def test_batch_discriminated_whole_streams_against_c_oracle(dsp, batchmod):
+    """`discriminated` over WHOLE streams (33 blocks each, four streams incl. a quiet and a loud one), every
+    sample, against the C oracle's float64 values: the 1e-5 bound of the north_star on more than the three blocks
+    the fixture holds."""
+    from oracle import c_oracle as CO
+    seeds = [3, 17, 42, 63]
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    bd.demodulate(raw)
+    n = raw.shape[1] // 2
+    worst = 0.0
+    for i in range(len(seeds)):
+        _, _, ref = CO.demod_stream(raw[i], CO.make_cfg(), want_disc=True)
+        got = bd.discriminated(i, 0, n)
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        worst = max(worst, float(err.max()))
+        assert np.all(err <= 1e-5), f"stream {i}: {err.max()} at {int(err.argmax())}"
+    assert worst < 1e-5
