@@ -69,15 +69,16 @@ __device__ __forceinline__ rd_h8 rd_mf_frag(rd_u2v d) {
     return __builtin_bit_cast(rd_h8, v);
 }
 
-// -(ar cr + ai ci): numerator of py:89 for n = (ar, ai), n+ = (cr, ci) in the g frame; also
-// r = |num| - 2^-21 |ai ci|, the numerator less the part of its error bound that scales with the
-// products (rd_mfma.h): one more fma, with free abs / neg modifiers.
-__device__ __forceinline__ float rd_mf_num(float ar, float ai, float cr, float ci, float &r) {
-    const float t1 = ai * ci;
-    const float num = __builtin_fmaf(-ar, cr, -t1);
-    r = __builtin_fmaf(-4.76837158e-7f, __builtin_fabsf(t1), __builtin_fabsf(num));
-    return num;
+// -(ar cr + ai ci): numerator of py:89 for n = (ar, ai), n+ = (cr, ci) in the g frame; t1 = ai ci, the product
+// whose size sets the part of the error bound that scales with the products (rd_mfma.h).
+__device__ __forceinline__ float rd_mf_num(float ar, float ai, float cr, float ci, float &t1) {
+    t1 = ai * ci;
+    return __builtin_fmaf(-ar, cr, -t1);
 }
+// The guard value of a GROUP: min |num| - 2^-21 max |t1| <= |num_i| - 2^-21 |t1_i| for every sample of the group,
+// so a group that passes with it passes sample by sample (rd_mfma.h); two three-operand min / max per pair of
+// samples and one fma per group instead of an fma per sample.
+__device__ __forceinline__ float rd_mf_guard(float nmin, float tmax) { return __builtin_fmaf(-4.76837158e-7f, tmax, nmin); }
 // min(m, a, b) without abs (r may be negative: then the group is inside the band anyway)
 __device__ __forceinline__ float rd_min3(float m, float a, float b) {
     float o;
@@ -190,14 +191,15 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     }
     rd_f4v p = {0.0f, 0.0f, 0.0f, 0.0f};
     if (B > 0) p = rd_lds_read16<0>(xr);  // g[base-1], g[base]: in flight under the group's own work
-    float nm = 3.0e38f;
+    float nmin = 3.0e38f, tmax = 0.0f;
     uint32_t w6 = 0;
 #pragma unroll
     for (int q = 2; q < 8; q += 2) {
-        float ra, rb;
-        const float na = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1], ra);
-        const float nb = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1], rb);
-        nm = rd_min3(nm, ra, rb);
+        float ta, tb;
+        const float na = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1], ta);
+        const float nb = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1], tb);
+        nmin = rd_min3abs(nmin, na, nb);
+        tmax = rd_max3abs(tmax, ta, tb);
         w6 = rd_shift_in_sign(w6, na);
         w6 = rd_shift_in_sign(w6, nb);
     }
@@ -206,15 +208,17 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
         st.W = w6;
     } else {
         rd_lds_wait(p);
-        float r0, r1;
-        const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, r0);
-        const float n1 = rd_mf_num(p.z, p.w, g[0], g[1], r1);
-        nm = rd_min3(nm, r0, r1);
+        float t0, t1;
+        const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, t0);
+        const float n1 = rd_mf_num(p.z, p.w, g[0], g[1], t1);
+        nmin = rd_min3abs(nmin, n0, n1);
+        tmax = rd_max3abs(tmax, t0, t1);
         uint32_t w2 = rd_shift_in_sign(0u, n0);
         w2 = rd_shift_in_sign(w2, n1);
         st.W = (st.W << 8) | (w2 << 6) | w6;
     }
     if (DBG == 0 || DBG == 3) {
+        const float nm = rd_mf_guard(nmin, tmax);
         if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {  // rare; NaN counts as inside
             float F = 0.0f;
 #pragma unroll
@@ -440,13 +444,13 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
             {   // block 0's first two numerators: W holds 30 bits, its bits 31, 30 are theirs
                 rd_f4v p = rd_lds_read16<0>(xr0);
                 rd_lds_wait(p);
-                float r0, r1;
-                const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, r0);
-                const float n1 = rd_mf_num(p.z, p.w, stt.g0r, stt.g0i, r1);
+                float t0, t1;
+                const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, t0);
+                const float n1 = rd_mf_num(p.z, p.w, stt.g0r, stt.g0i, t1);
                 stt.W |= __builtin_bit_cast(uint32_t, n0) & 0x80000000u;
                 stt.W |= (__builtin_bit_cast(uint32_t, n1) >> 1) & 0x40000000u;
                 if (DBG == 0 || DBG == 3) {
-                    const float nm = rd_min3(3.0e38f, r0, r1);
+                    const float nm = rd_mf_guard(rd_min3abs(3.0e38f, n0, n1), rd_max3abs(0.0f, t0, t1));
                     if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {
                         float F = rd_max3abs(0.0f, p.x, p.y);
                         F = rd_max3abs(F, p.z, p.w);

@@ -60,6 +60,9 @@
 // so the sign of N_hat is the sign of the exact N whenever
 //   r := |N_hat| - 2^-21 |t1|  >  rd_mf_c0(F) := (4 E0 F + 3e-10) * (1 + 2^-19)
 // (the factor covers the 2^-22 |N_hat| term and the fp32 rounding of r and of this expression).
+// The kernel tests GROUPS of eight samples with r_group = min_i |N_hat_i| - 2^-21 max_i |t1_i| <= every r_i
+// (two three-operand min / max per pair of samples, one fma per group), against rd_mf_c0 at F = the largest
+// |component| any input can produce and, in the rare wave that fails there, at the F of the values at hand.
 // rd_mf_threshold(F) = F (4 E0 + 2^-21 F) + 3e-10 is the cruder form |N_hat| > ... with |t1| <= F^2; kept for
 // the host-side model.
 #if defined(__HIPCC__)
