@@ -576,8 +576,15 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     }
     // (three workgroups per CU instead of the four that fit: within the run-to-run noise, +-2 %)
     const int per_cu = (per_cu_env >= 1 && per_cu_env <= 8) ? per_cu_env : per_cu_occ[variant];
-    // default 12: a multiple of the 4-tile store groups that divides the 132 tiles of a 33-block stream
-    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : 12;
+    // Tiles per chunk: a multiple of the 4-tile store groups.  Measured on 4096 x 132 tiles (two boxes, r02
+    // chunk sweep in DESIGN section 5): 28 is 4 % faster than 12 and than every other value between 8 and 66 -
+    // 12, 33, 44, 66 (whole numbers of rounds over the persistent waves) are the slow ones.  A small workload
+    // gets shorter chunks, down to one store group, until every resident wave has one.
+    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : 28;
+    if (chunk_env <= 0) {
+        const uint64_t waves = (uint64_t)n_cu * per_cu * RD_MF_WAVES;
+        while (chunk > RD_MF_STAGE_TILES && total64 / chunk < waves) chunk -= RD_MF_STAGE_TILES;
+    }
     if (chunk > total) chunk = total;
     const uint64_t chunks = (total64 + chunk - 1) / chunk;
     uint64_t wgs = (chunks + RD_MF_WAVES - 1) / RD_MF_WAVES;

@@ -309,7 +309,9 @@ def test_full_size_4096_streams_properties(dsp, batchmod, golden_streams):
     assert len(crc_unique) == 64 and total == 586
     cnt = bd.counters()
     assert cnt["matches"] % 64 == 0  # 64 identical copies of each unique stream
-    assert 0 < cnt["fixup_runs"] < 0.05 * 4096 * 8448 and cnt["fixup_runs"] % 64 == 0
+    # (the fix-up list is not a multiple of 64: the forced entries at chunk starts follow the global tile index,
+    # 28 tiles per chunk against 132 per stream)
+    assert 0 < cnt["fixup_runs"] < 0.05 * 4096 * 8448
 
 
 # ---------------------------------------------------------------- streaming Demodulator
