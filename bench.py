@@ -267,9 +267,11 @@ def main():
     # kernel's persistent grid leaves no room for another batch's kernels to run beside it
     tstreams = [torch.cuda.Stream() for _ in bds] if args.two_streams else [torch.cuda.current_stream()] * len(bds)
     streams = [t.cuda_stream for t in tstreams]
-    for x in bds:
-        x.set_timing(2 if args.stage_times else 1)  # 1: demod kernel + whole run (an event between two
-        # kernels idles the GPU for ~6 us, so the per-stage split is opt-in and comes from rocprofv3)
+    # Kernel timing (HIP events riding on the dispatches) is switched on right in front of the timed region:
+    # the settle and warmup steps run untimed, so there are no event pairs to read back - a read-back of a
+    # hundred of them idles the GPU long enough for its clock to drop again.
+    timing_level = 2 if args.stage_times else 1  # 1: demod kernel + whole run (an event between two
+    # kernels idles the GPU for ~6 us, so the per-stage split is opt-in and comes from rocprofv3)
 
     R = len(bds)
 
@@ -309,7 +311,7 @@ def main():
         run_steps(args.warmup)
     sync_all()
     for x in bds:
-        x.timing()  # start a fresh timing window: events of the K timed steps only
+        x.set_timing(timing_level)  # the timing window holds the K timed steps only
     t0 = time.perf_counter()
     recs, bd = run_steps(args.steps)
     sync_all()
