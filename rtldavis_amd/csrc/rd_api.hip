@@ -247,6 +247,7 @@ struct rd_batch {
     size_t iq_bytes = 0;
     uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
     rd_match *d_matches = nullptr;
+    void *d_tasks = nullptr;         // rec_cap entries of RD_TASK_BYTES (two-kernel slice)
     rd_packet *d_recs = nullptr;     // rec_cap = 2 * match_cap entries (layout: rd_launch_slice)
     int cnt_set = 0;                 // d_cnt holds two counter sets; a run's fixup kernel clears the other one
     bool parse = false;              // Parser.parse front half on the device (rd_batch_set_parse)
@@ -333,6 +334,7 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMemset(b->d_cnt, 0, 2 * RD_CNT_SLOTS * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+    HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
     HIPCHK(hipHostMalloc((void **)&b->h_cnt_pin, RD_CNT_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
     b->rec_pin_cap = b->rec_cap;
@@ -348,7 +350,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
     if (b->dev_ready && g_hip_pid == getpid()) {
         if (b->device >= 0) hipSetDevice(b->device);
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
-        hipFree(b->d_matches); hipFree(b->d_recs);
+        hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
@@ -390,7 +392,7 @@ static int batch_search_slice(rd_batch *b, hipStream_t st) {
     hipEvent_t last = b->run_timing ? b->ev[4] : b->kdone;
     const bool last_on_slice = !b->parse;
     rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
-                    b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr);
+                    b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr, b->d_tasks);
     if (b->parse) {
         if (!b->d_parsed) HIPCHK(hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed)));
         rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
@@ -478,11 +480,13 @@ static int batch_finish(rd_batch *b) {
         }
         if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
             hipFree(b->d_matches); hipFree(b->d_recs); hipHostFree(b->h_recs_pin);
+            hipFree(b->d_tasks); b->d_tasks = nullptr;
             hipFree(b->d_parsed); b->d_parsed = nullptr;
             b->match_cap = b->h_cnt[RD_CNT_MATCH] + b->h_cnt[RD_CNT_MATCH] / 4 + 1024;
             b->rec_cap = 2 * b->match_cap;
             HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
             HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
+            HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
             HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
             b->rec_pin_cap = b->rec_cap;
             redo_search = true;

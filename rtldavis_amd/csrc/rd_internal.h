@@ -8,7 +8,7 @@
 // counters[] slots (device uint32)
 // FIX: flagged runs; MATCH: preamble matches (= primary records); REC: second records of
 // block-boundary positions; PARSED: CRC-valid messages
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
 
 // Geometry of the fused demod kernel
 #define RD_TILE_SAMPLES 2048  // 64 lanes x 32 samples: one wave iteration
@@ -71,7 +71,9 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
                      rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st,
-                     hipEvent_t ev_stop = nullptr);
+                     hipEvent_t ev_stop = nullptr, void *tasks = nullptr);
+// tasks: 2 * match_cap entries of RD_TASK_BYTES (the two-kernel form of the batch path; null: one kernel)
+#define RD_TASK_BYTES 16
 // Parser.parse front half (protocol.py:290-311) over the records of a batch run (layout as
 // above): CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
 void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,

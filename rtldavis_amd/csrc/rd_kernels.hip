@@ -16,6 +16,7 @@
 // HBM-bound scan: no MFMA (there is no dense contraction).  The input is read once with
 // 16-byte coalesced global->LDS loads; each lane then owns 32 consecutive samples so the
 // 9-tap window lives in registers and one lane emits one packed 32-bit word.
+#include <algorithm>
 #include <cstdlib>
 
 #include <hip/hip_ext.h>
@@ -839,6 +840,154 @@ __global__ __launch_bounds__(256, RD_SLICE_MIN_WGS) void k_slice_rssi(Src src, c
     }
 }
 
+__device__ __forceinline__ uint32_t rd_wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(v, o, 64);
+        if (lane >= o) v += up;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same work in two kernels for a compile-time (S, K) and the batch path: k_classify takes one LANE per match -
+// the wave-per-match kernel above spends ~80 instructions and a chain of three memory latencies on a match that
+// two times out of three is voided - and k_rssi one wave per SURVIVING packet (its two RSSI windows are 448 filter
+// outputs).  A lane reads the words that hold its packet's K symbols for positions pos-1, pos, pos+1, shifts them
+// to a common origin, and then everything is static: symbol k sits at bit k S + 1.
+// ------------------------------------------------------------------------------------------
+struct rd_task {
+    uint32_t rec;     // record index (primary slot, or match_cap + extra slot)
+    int32_t stream;
+    int32_t call;     // reported by this call ...
+    int32_t q;        // ... at this window index
+};
+
+template <int S_, int K_>
+__global__ __launch_bounds__(256) void k_classify(const uint32_t *bits, size_t bits_stride, int nwords, rd_devcfg cfg,
+                                                  const rd_match *matches, uint32_t match_cap, int n_calls,
+                                                  rd_packet *recs, rd_task *tasks, uint32_t *counters) {
+    constexpr int NBITS = (K_ - 1) * S_ + 3;          // bits pos-1 .. of the three packets
+    constexpr int NU = (NBITS + 31) / 32;              // words of the aligned stream
+    constexpr int NW = NU + 1;                         // words fetched (funnel)
+    constexpr int NBYTES = (K_ + 7) / 8;
+    static_assert(K_ % 8 == 0 && NBYTES <= RD_MAX_PKT_BYTES, "whole bytes only");
+    const int lane = threadIdx.x & 63;
+    uint32_t count = counters[RD_CNT_MATCH];
+    if (count > match_cap) count = match_cap;
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) - lane;  // the wave's first index: wave-uniform trips
+    for (uint32_t i0 = first; i0 < count; i0 += nthreads) {
+        const uint32_t i = i0 + lane;
+        const bool live = i < count;
+        int stream = 0, pos = 0;
+        if (live) { stream = matches[i].stream; pos = matches[i].pos; }
+        // calls that report this position (py:194, q <= B), as in k_slice_rssi
+        const uint32_t pl = (uint32_t)(pos + cfg.L), bq = pl / (uint32_t)cfg.B, br = pl - bq * (uint32_t)cfg.B;
+        const int b0 = (int)bq - 1;
+        const int q0 = pos - ((b0 + 1) * cfg.B - cfg.L);
+        const bool ok0 = live && b0 >= 0 && b0 < n_calls;
+        const int b1 = b0 - 1, q1 = q0 + cfg.B;
+        const bool ok1 = live && br == 0 && b1 >= 0 && b1 < n_calls;
+        // words holding bits pos-1 ..: zero outside the array (rd_bits32_at_i)
+        const uint32_t *w = bits + (size_t)stream * bits_stride;
+        const int o = pos - 1, wi0 = o >> 5;
+        const uint32_t sh = (uint32_t)(o & 31);
+        uint32_t W[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const int wi = wi0 + j;
+            W[j] = (live && wi >= 0 && wi < nwords) ? w[wi] : 0u;
+        }
+        uint32_t u[NU];
+#pragma unroll
+        for (int j = 0; j < NU; j++) u[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], sh);
+        // symbol k of position pos-1 / pos / pos+1 = bit k S / k S + 1 / k S + 2 of u.
+        // y = u ^ (u >> 1): bit kS set <=> prev differs from cur, bit kS + 1 set <=> cur differs from next
+        uint32_t dprev = 0, dnext = 0;
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            const uint32_t nxt = j + 1 < NU ? u[j + 1] : 0u;
+            const uint32_t y = u[j] ^ __builtin_amdgcn_alignbit(nxt, u[j], 1);
+            uint32_t mp = 0, mn = 0;  // static masks of this word
+#pragma unroll
+            for (int k = 0; k < K_; k++) {
+                if (((k * S_) >> 5) == j) mp |= 1u << ((k * S_) & 31);
+                if (((k * S_ + 1) >> 5) == j) mn |= 1u << ((k * S_ + 1) & 31);
+            }
+            dprev |= y & mp;
+            dnext |= y & mn;
+        }
+        const bool same_prev = dprev == 0, same_next = dnext == 0;
+        // the packet's bytes: byte bi = symbols 8 bi .. 8 bi + 7, first symbol = MSB (py:197-200)
+        uint32_t dw[(NBYTES + 3) / 4];
+#pragma unroll
+        for (int m = 0; m < (NBYTES + 3) / 4; m++) dw[m] = 0;
+#pragma unroll
+        for (int k = 0; k < K_; k++) {
+            const int bit = k * S_ + 1, bi = k >> 3;
+            const uint32_t b = (u[bit >> 5] >> (bit & 31)) & 1u;
+            dw[bi >> 2] |= b << (8 * (bi & 3) + 7 - (k & 7));
+        }
+        auto superseded = [&](int q) {
+            const uint32_t S = (uint32_t)S_, ph = (uint32_t)q % S;
+            const bool prev_first = S == 1 || ph != 0;
+            const bool next_first = S > 1 && ph == S - 1;
+            return (same_prev && q >= 1 && prev_first) || (same_next && q + 1 <= cfg.B && next_first);
+        };
+        const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);
+        const int ntask = (use0 ? 1 : 0) + (use1 ? 1 : 0);
+        if (live && ntask == 0) recs[i].stream = -1;
+        // task slots: one atomic per wave
+        const uint32_t incl = rd_wave_incl_scan_u32((uint32_t)ntask, lane);
+        const uint32_t tot = __shfl(incl, 63, 64);
+        if (tot == 0) continue;  // wave-uniform
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&counters[RD_CNT_TASKS], tot);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ntask) {
+            uint32_t t = base + incl - (uint32_t)ntask;
+            const int pb = use0 ? b0 : b1, pq = use0 ? q0 : q1;
+            auto put = [&](uint32_t ri, int call, int q) {
+                uint32_t *r = (uint32_t *)&recs[ri];
+                const uint4 hdr = {(uint32_t)stream, (uint32_t)call, (uint32_t)q, (uint32_t)NBYTES};
+                *(uint4 *)r = hdr;
+                uint32_t d8[RD_MAX_PKT_BYTES / 4];
+#pragma unroll
+                for (int m = 0; m < RD_MAX_PKT_BYTES / 4; m++) d8[m] = m < (NBYTES + 3) / 4 ? dw[m] : 0u;
+#pragma unroll
+                for (int m = 0; m < RD_MAX_PKT_BYTES / 16; m++)
+                    *(uint4 *)(r + 4 + 4 * m) = uint4{d8[4 * m], d8[4 * m + 1], d8[4 * m + 2], d8[4 * m + 3]};
+                const rd_task tk = {ri, stream, call, q};
+                tasks[t++] = tk;
+            };
+            put(i, pb, pq);
+            if (use0 && use1) {
+                const uint32_t xslot = atomicAdd(&counters[RD_CNT_REC], 1u);  // rare: a position on a block boundary
+                put(match_cap + xslot, b1, q1);
+            }
+        }
+    }
+}
+
+template <class Src>
+__global__ __launch_bounds__(256) void k_rssi(Src src, rd_devcfg cfg, const rd_task *tasks, uint32_t task_cap,
+                                              rd_packet *recs, const uint32_t *counters) {
+    const int lane = threadIdx.x & 63;
+    uint32_t count = counters[RD_CNT_TASKS];
+    if (count > task_cap) count = task_cap;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
+        const uint32_t rec = __builtin_amdgcn_readfirstlane(tasks[i].rec);
+        const int stream = __builtin_amdgcn_readfirstlane(tasks[i].stream);
+        const long call = __builtin_amdgcn_readfirstlane(tasks[i].call);
+        const long q = __builtin_amdgcn_readfirstlane(tasks[i].q);
+        double rssi = 0.0, snr = 0.0;
+        src.rssi(stream, call * cfg.B, cfg, q, lane, rssi, snr);
+        if (lane == 0) { recs[rec].rssi = rssi; recs[rec].snr = snr; }
+    }
+}
+
 static uint32_t rd_slice_grid(uint32_t match_cap) {
     uint32_t wgs = (match_cap + 3) / 4;
     if (wgs > 4096) wgs = 4096;
@@ -847,9 +996,26 @@ static uint32_t rd_slice_grid(uint32_t match_cap) {
 
 void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop) {
+                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop,
+                     void *tasks) {
     rd_u8_src src;
     src.lay = lay;
+    static int two = -1;
+    if (two < 0) { const char *e = getenv("RD_SLICE_IMPL"); two = (e && e[0] == 'w') ? 0 : 1; }  // "wave": the one-kernel form (A/B)
+    // the Davis shape in the batch path: lane-per-match classification, then one wave per surviving packet
+    if (two && tasks && batch_mode && recs && !recs_host && cfg.S == 14 && cfg.K == 80 && n_bits < (1l << 30)) {
+        const uint32_t cg = std::min<uint32_t>((match_cap + 255) / 256, 1024);
+        hipLaunchKernelGGL((k_classify<14, 80>), dim3(cg ? cg : 1), dim3(256), 0, st, bits, bits_stride,
+                           (int)((n_bits + 31) / 32), cfg, matches, match_cap, n_calls, recs, (rd_task *)tasks, counters);
+        const uint32_t rg = rd_slice_grid(match_cap);
+        if (ev_stop)
+            hipExtLaunchKernelGGL(k_rssi<rd_u8_src>, dim3(rg), dim3(256), 0, st, nullptr, ev_stop, 0, src, cfg,
+                                  (const rd_task *)tasks, 2 * match_cap, recs, counters);
+        else
+            hipLaunchKernelGGL(k_rssi<rd_u8_src>, dim3(rg), dim3(256), 0, st, src, cfg, (const rd_task *)tasks,
+                               2 * match_cap, recs, counters);
+        return;
+    }
     if (ev_stop)  // the dispatch records the event itself (no marker packet behind the kernel)
         hipExtLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, nullptr,
                               ev_stop, 0, src, bits, bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap,
