@@ -23,6 +23,7 @@
 
 #include "rd_internal.h"
 #include "rd_math.h"
+#include "rd_mfma.h"
 
 #define RD_WG 256
 #define RD_WAVES (RD_WG / 64)
@@ -674,6 +675,105 @@ __device__ __forceinline__ float rd_wave_sum_f32(float v) {
     return v;  // valid in lane 0
 }
 
+// The RSSI windows on the matrix pipe: the 448 filter outputs of a packet's two windows are ONE 16-output block of
+// 32 columns in rd_mfma.h's formulation (six MFMAs, exact; rd_demod_mfma.hip: rd_mf_block) instead of 144 fp32
+// fma per lane.  Column n covers outputs A + 16 n + 1 .. A + 16 n + 16, lane (n, h) its half h; A is the
+// window's first output rounded down to a multiple of four samples (8-byte aligned loads).  Applies when every
+// sample the 32 columns touch is a real byte of the stream; otherwise the caller's fp32 path runs.
+typedef _Float16 rd_k_h8 __attribute__((ext_vector_type(8)));
+typedef float rd_k_f16v __attribute__((ext_vector_type(16)));
+__device__ const rd_mf_taps g_rssi_taps = rd_mf_make_taps();
+
+__device__ __forceinline__ rd_k_h8 rd_k_frag(uint2 d) {  // as rd_mf_frag: a byte read as an f16 pattern is k * 2^-24
+    uint4 v;
+    v.x = d.x & 0x00FF00FFu;
+    v.y = __builtin_amdgcn_perm(0u, d.x, 0x0c030c01u);
+    v.z = d.y & 0x00FF00FFu;
+    v.w = __builtin_amdgcn_perm(0u, d.y, 0x0c030c01u);
+    return __builtin_bit_cast(rd_k_h8, v);
+}
+
+// One RSSI job prepared for the matrix pipe: ok = every sample the 32 columns touch is a real byte of the stream
+// (wave-uniform); p = this lane's first 8 window bytes.
+struct rd_rssi_job {
+    bool ok;
+    int A, ns, pe, q, origin;
+    const uint8_t *p;
+};
+__device__ __forceinline__ rd_rssi_job rd_rssi_prepare(const rd_stream_view &v, int origin, const rd_devcfg &cfg, int q, int lane) {
+    rd_rssi_job j;
+    j.origin = origin; j.q = q;
+    j.ns = q - cfg.PL < 0 ? 0 : q - cfg.PL;
+    j.pe = q + cfg.PL > cfg.B + 1 ? cfg.B + 1 : q + cfg.PL;
+    const int t_lo = origin + j.ns - 1, t_hi = origin + j.pe - 2;  // filter outputs f[t] of the window
+    j.A = (t_lo - 1) & ~3;
+    j.ok = t_lo >= 1 && j.A - 8 >= (int)v.valid_from && j.A + 16 * 31 + 24 <= (int)v.n + 8 && t_hi <= j.A + 512;
+    j.p = v.base + 2 * (long)(j.A - 8) + 32 * (lane & 31) + 8 * (lane >> 5);
+    return j;
+}
+struct rd_rssi_data {
+    uint2 d0, d1, d2;
+};
+__device__ __forceinline__ rd_rssi_data rd_rssi_fetch(const rd_rssi_job &j) {
+    rd_rssi_data d;
+    d.d0 = *(const uint2 *)j.p; d.d1 = *(const uint2 *)(j.p + 16); d.d2 = *(const uint2 *)(j.p + 32);
+    return d;
+}
+// window sums of |f|^2 (noise: window index < q, signal: the rest) from the fetched bytes
+__device__ __forceinline__ void rd_rssi_block(const rd_rssi_job &j, const rd_rssi_data &d, const rd_k_h8 (&Ahi)[3],
+                                              const rd_k_h8 (&Alo)[3], int lane, float &noise, float &sig) {
+    const int n = lane & 31, h = lane >> 5;
+    const float dcv = -(float)RD_MF_DHI / 16777216.0f;
+    const rd_k_f16v dc = {dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv, dcv};
+    const rd_k_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const rd_k_h8 b0 = rd_k_frag(d.d0), b1 = rd_k_frag(d.d1), b2 = rd_k_frag(d.d2);
+    rd_k_f16v ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[0], b0, dc, 0, 0, 0);
+    rd_k_f16v al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], b0, zero, 0, 0, 0);
+    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], b1, ah, 0, 0, 0);
+    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], b1, al, 0, 0, 0);
+    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], b2, ah, 0, 0, 0);
+    al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], b2, al, 0, 0, 0);
+    // |f|^2 = |g|^2 / (127.6 * 2^-24 S)^2: g is the filter output in rd_mfma.h's units, the rotation has modulus 1
+    const float inv = (float)(1.0 / (127.6 * RD_MF_G_PER_BYTE * 127.6 * RD_MF_G_PER_BYTE));
+    float sn = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float gr = __builtin_fmaf(ah[2 * r], 2048.0f, al[2 * r]), gi = __builtin_fmaf(ah[2 * r + 1], 2048.0f, al[2 * r + 1]);
+        const float pw = __builtin_fmaf(gr, gr, gi * gi);
+        const int jj = j.A + 16 * n + 8 * h + 1 + r - j.origin + 1;  // window index of output t
+        if (jj >= j.ns && jj < j.pe) { if (jj < j.q) sn += pw; else ss += pw; }
+    }
+    noise = sn * inv;
+    sig = ss * inv;
+}
+
+// Sum over the wave without the LDS crossbar: four rotations inside the rows of 16 lanes (DPP), then the four row
+// sums through scalar registers - a dozen short-latency instructions instead of six dependent ds_bpermute.
+__device__ __forceinline__ float rd_wave_sum_dpp(float v) {
+#define RD_ROR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), 0x120 + (n), 0xF, 0xF, false))
+    v += RD_ROR(v, 1);
+    v += RD_ROR(v, 2);
+    v += RD_ROR(v, 4);
+    v += RD_ROR(v, 8);
+#undef RD_ROR
+    const int vi = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+}
+
+// per-lane partial sums -> py:207-236's two figures (valid in lane 0)
+__device__ __forceinline__ void rd_rssi_finish(float noise, float sig, int ns, int pe, int q, int lane, double &rssi, double &snr) {
+    noise = rd_wave_sum_dpp(noise);
+    sig = rd_wave_sum_dpp(sig);
+    if (lane == 0) {
+        const float noise_power = (q > ns) ? noise / (float)(q - ns) : 1e-9f;
+        const float signal_power = (pe > q) ? sig / (float)(pe - q) : __builtin_nanf("");
+        // 10*log10(x) = 3.0102999566 * log2(x)
+        rssi = signal_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power)) : -120.0;
+        snr = noise_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power / noise_power)) : 50.0;
+    }
+}
+
 // uint8 input: the window means are evaluated in fp32 (|f|^2 to ~1e-6 relative; 10*log10 through
 // v_log_f32, ~3e-6 dB; the tolerance on RSSI/SNR is 1e-3 dB).
 __device__ __forceinline__ void rd_rssi_u8(const rd_stream_view &v, long origin64, const rd_devcfg &cfg, long q64,
@@ -698,15 +798,7 @@ __device__ __forceinline__ void rd_rssi_u8(const rd_stream_view &v, long origin6
             }
         }
     }
-    noise = rd_wave_sum_f32(noise);
-    sig = rd_wave_sum_f32(sig);
-    if (lane == 0) {
-        const float noise_power = (q > ns) ? noise / (float)(q - ns) : 1e-9f;
-        const float signal_power = (pe > q) ? sig / (float)(pe - q) : __builtin_nanf("");
-        // 10*log10(x) = 3.0102999566 * log2(x)
-        rssi = signal_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power)) : -120.0;
-        snr = noise_power > 0 ? (double)(3.0102999566f * __builtin_amdgcn_logf(signal_power / noise_power)) : 50.0;
-    }
+    rd_rssi_finish(noise, sig, ns, pe, q, lane, rssi, snr);
 }
 
 #ifndef RD_SLICE_MIN_WGS
@@ -872,13 +964,14 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *bits, size_t b
     constexpr int NW = NU + 1;                         // words fetched (funnel)
     constexpr int NBYTES = (K_ + 7) / 8;
     static_assert(K_ % 8 == 0 && NBYTES <= RD_MAX_PKT_BYTES, "whole bytes only");
+    __shared__ uint32_t s_tot[4], s_base;
     const int lane = threadIdx.x & 63;
     uint32_t count = counters[RD_CNT_MATCH];
     if (count > match_cap) count = match_cap;
     const uint32_t nthreads = gridDim.x * blockDim.x;
-    const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) - lane;  // the wave's first index: wave-uniform trips
-    for (uint32_t i0 = first; i0 < count; i0 += nthreads) {
-        const uint32_t i = i0 + lane;
+    // trips are uniform over the WORKGROUP (barriers inside): the workgroup's first index decides
+    for (uint32_t g0 = blockIdx.x * blockDim.x; g0 < count; g0 += nthreads) {
+        const uint32_t i = g0 + threadIdx.x;
         const bool live = i < count;
         int stream = 0, pos = 0;
         if (live) { stream = matches[i].stream; pos = matches[i].pos; }
@@ -938,12 +1031,24 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *bits, size_t b
         const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);
         const int ntask = (use0 ? 1 : 0) + (use1 ? 1 : 0);
         if (live && ntask == 0) recs[i].stream = -1;
-        // task slots: one atomic per wave
+        // task slots: ONE atomic per workgroup and trip (a counter word sustains ~90 atomics per microsecond: one per
+        // wave was 12 of this kernel's 20 us).  All waves of a workgroup make the same number of trips.
         const uint32_t incl = rd_wave_incl_scan_u32((uint32_t)ntask, lane);
         const uint32_t tot = __shfl(incl, 63, 64);
-        if (tot == 0) continue;  // wave-uniform
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[RD_CNT_TASKS], tot);
+        const int wv = threadIdx.x >> 6;
+        __syncthreads();  // the previous trip's s_tot / s_base have been read
+        if (lane == 0) s_tot[wv] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum += s_tot[k];
+            s_base = sum ? atomicAdd(&counters[RD_CNT_TASKS], sum) : 0u;
+        }
+        __syncthreads();
+        uint32_t base = s_base;
+#pragma unroll
+        for (int k = 0; k < 4; k++) base += k < wv ? s_tot[k] : 0u;
         base = __builtin_amdgcn_readfirstlane(base);
         if (ntask) {
             uint32_t t = base + incl - (uint32_t)ntask;
@@ -970,20 +1075,64 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *bits, size_t b
     }
 }
 
-template <class Src>
-__global__ __launch_bounds__(256) void k_rssi(Src src, rd_devcfg cfg, const rd_task *tasks, uint32_t task_cap,
-                                              rd_packet *recs, const uint32_t *counters) {
+// One wave per surviving packet.  The task entry two steps ahead and the window bytes of the next step are
+// fetched while the current packet's block runs on the matrix pipe: the kernel is a chain of latencies otherwise.
+__global__ __launch_bounds__(256) void k_rssi_u8(rd_layout lay, rd_devcfg cfg, const rd_task *tasks, uint32_t task_cap,
+                                                 rd_packet *recs, const uint32_t *counters) {
     const int lane = threadIdx.x & 63;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    const uint32_t i0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    rd_k_h8 Ahi[3], Alo[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
+        Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
+    }
+    rd_task t_cur = {0, 0, 0, 0}, t_nxt = {0, 0, 0, 0};
+    if (i0 < task_cap) t_cur = tasks[i0];                 // (any index below task_cap is readable)
+    if (i0 + nw < task_cap) t_nxt = tasks[i0 + nw];
     uint32_t count = counters[RD_CNT_TASKS];
     if (count > task_cap) count = task_cap;
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < count; i += nw) {
-        const uint32_t rec = __builtin_amdgcn_readfirstlane(tasks[i].rec);
-        const int stream = __builtin_amdgcn_readfirstlane(tasks[i].stream);
-        const long call = __builtin_amdgcn_readfirstlane(tasks[i].call);
-        const long q = __builtin_amdgcn_readfirstlane(tasks[i].q);
+    auto view = [&](int stream) {
+        rd_stream_view v;
+        v.base = lay.iq + (size_t)stream * lay.stream_stride;
+        v.valid_from = lay.valid_from;
+        v.n = lay.n_samples;
+        return v;
+    };
+    auto job_of = [&](const rd_task &t) {
+        const int stream = __builtin_amdgcn_readfirstlane(t.stream), call = __builtin_amdgcn_readfirstlane(t.call),
+                  q = __builtin_amdgcn_readfirstlane(t.q);
+        return rd_rssi_prepare(view(stream), call * cfg.B, cfg, q, lane);
+    };
+    rd_rssi_job j_cur = {};
+    rd_rssi_data d_cur = {};
+    if (i0 < count) {
+        j_cur = job_of(t_cur);
+        if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+    }
+    for (uint32_t i = i0; i < count; i += nw) {
+        const rd_task t_now = t_cur;
+        const rd_rssi_job j_now = j_cur;
+        const rd_rssi_data d_now = d_cur;
+        // next step's bytes, the entry after that
+        if (i + nw < count) {
+            j_cur = job_of(t_nxt);
+            if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+        }
+        t_cur = t_nxt;
+        if (i + 2 * nw < task_cap) t_nxt = tasks[i + 2 * nw];
+        const uint32_t rec = __builtin_amdgcn_readfirstlane(t_now.rec);
         double rssi = 0.0, snr = 0.0;
-        src.rssi(stream, call * cfg.B, cfg, q, lane, rssi, snr);
+        if (j_now.ok) {
+            float noise, sig;
+            rd_rssi_block(j_now, d_now, Ahi, Alo, lane, noise, sig);
+            rd_rssi_finish(noise, sig, j_now.ns, j_now.pe, j_now.q, lane, rssi, snr);
+        } else {  // a window that reaches outside the stream: the fp32 path with its per-sample checks
+            const int stream = __builtin_amdgcn_readfirstlane(t_now.stream);
+            rd_rssi_u8(view(stream), (long)__builtin_amdgcn_readfirstlane(t_now.call) * cfg.B, cfg,
+                       (long)__builtin_amdgcn_readfirstlane(t_now.q), lane, rssi, snr);
+        }
         if (lane == 0) { recs[rec].rssi = rssi; recs[rec].snr = snr; }
     }
 }
@@ -1007,12 +1156,14 @@ void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_str
         const uint32_t cg = std::min<uint32_t>((match_cap + 255) / 256, 1024);
         hipLaunchKernelGGL((k_classify<14, 80>), dim3(cg ? cg : 1), dim3(256), 0, st, bits, bits_stride,
                            (int)((n_bits + 31) / 32), cfg, matches, match_cap, n_calls, recs, (rd_task *)tasks, counters);
-        const uint32_t rg = rd_slice_grid(match_cap);
+        // one resident generation of waves (4 per SIMD): each works through its ~6 packets with the next one's
+        // bytes in flight; a larger grid means generations of waves that each pay the whole latency chain
+        const uint32_t rg = std::min<uint32_t>(rd_slice_grid(match_cap), 1024);
         if (ev_stop)
-            hipExtLaunchKernelGGL(k_rssi<rd_u8_src>, dim3(rg), dim3(256), 0, st, nullptr, ev_stop, 0, src, cfg,
+            hipExtLaunchKernelGGL(k_rssi_u8, dim3(rg), dim3(256), 0, st, nullptr, ev_stop, 0, lay, cfg,
                                   (const rd_task *)tasks, 2 * match_cap, recs, counters);
         else
-            hipLaunchKernelGGL(k_rssi<rd_u8_src>, dim3(rg), dim3(256), 0, st, src, cfg, (const rd_task *)tasks,
+            hipLaunchKernelGGL(k_rssi_u8, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_task *)tasks,
                                2 * match_cap, recs, counters);
         return;
     }
