@@ -305,7 +305,7 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
     return RD_OK;
 }
 
-static uint32_t *batch_cnt(const rd_batch *b) { return b->d_cnt + (size_t)b->cnt_set * RD_CNT_SLOTS; }
+static uint32_t *batch_cnt(const rd_batch *b) { return b->d_cnt + (size_t)b->cnt_set * RD_CNT_TOTAL; }
 
 // A handle is tied to the device that was current when its buffers were allocated; every entry point
 // makes that device current for the calling thread first (handles may be used from several threads).
@@ -330,8 +330,8 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));
     HIPCHK(hipMalloc(&b->d_bits, runs * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_fix, (size_t)b->fix_cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&b->d_cnt, 2 * RD_CNT_SLOTS * sizeof(uint32_t)));
-    HIPCHK(hipMemset(b->d_cnt, 0, 2 * RD_CNT_SLOTS * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b->d_cnt, 2 * RD_CNT_TOTAL * sizeof(uint32_t)));
+    HIPCHK(hipMemset(b->d_cnt, 0, 2 * RD_CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
     HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
@@ -428,7 +428,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     b->fetched = false;
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;
-    uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * RD_CNT_SLOTS;
+    uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * RD_CNT_TOTAL;
     b->run_timing = b->timing;  // set_timing between run() and results() does not touch the run in flight
     b->run_detail = b->timing_detail;
     if (b->timing) {
@@ -742,7 +742,7 @@ static int demod_alloc(rd_demod *h) {
         HIPCHK(hipMemset(h->d_win[i], 0, NS * ((L + 31) / 32) * 4));
     }
     HIPCHK(hipMalloc(&h->d_fix, (size_t)h->fix_cap * 4));
-    HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_SLOTS * 4));
+    HIPCHK(hipMalloc(&h->d_cnt, RD_CNT_TOTAL * 4));
     HIPCHK(hipMalloc(&h->d_matches, (size_t)h->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&h->d_tmp, 2 * (2 * B + 2) * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&h->h_tmp, 2 * (2 * B + 2) * sizeof(double), hipHostMallocDefault));
@@ -896,7 +896,7 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
             rd_launch_lut(sl.d_in, r + 32 + 2 * B, B, st);
         }
     }
-    HIPCHK(hipMemsetAsync(h->d_cnt, 0, RD_CNT_SLOTS * 4, st));
+    HIPCHK(hipMemsetAsync(h->d_cnt, 0, RD_CNT_TOTAL * 4, st));
     if (!h->cplx_mode) {
         const rd_layout lay = demod_layout(h, seen_before);
         if (h->fast_ok) rd_launch_demod(lay, h->d_fix, h->fix_cap, h->d_cnt, st);
@@ -1176,8 +1176,8 @@ extern "C" int rd_search(const rd_config *cfg, const uint8_t *quantized, size_t 
     HIPCHK(hipMalloc(&a.p, n));
     HIPCHK(hipMalloc(&w.p, ((n + 31) / 32) * 4));
     HIPCHK(hipMalloc(&m.p, (size_t)mcap * sizeof(rd_match)));
-    HIPCHK(hipMalloc(&cnt.p, RD_CNT_SLOTS * 4));
-    HIPCHK(hipMemset(cnt.p, 0, RD_CNT_SLOTS * 4));
+    HIPCHK(hipMalloc(&cnt.p, RD_CNT_TOTAL * 4));
+    HIPCHK(hipMemset(cnt.p, 0, RD_CNT_TOTAL * 4));
     HIPCHK(hipMemcpy(a.p, quantized, n, hipMemcpyHostToDevice));
     rd_launch_pack_bytes((const uint8_t *)a.p, (uint32_t *)w.p, n, nullptr);
     rd_launch_search((const uint32_t *)w.p, 0, 1, (long)n, 0, (long)n - 1 - span, dc, (rd_match *)m.p, mcap,

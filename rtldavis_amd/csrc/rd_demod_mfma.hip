@@ -284,21 +284,37 @@ __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t
     }
 }
 
-// position of a wave in its sequence of tiles: chunks of `chunk` consecutive tiles, nwaves chunks apart
+// Position of a wave in its sequence of tiles: chunks of `chunk` consecutive tiles.  A wave's first chunk is its
+// own number; the following ones come from work queues (rd_internal.h: RD_NQUEUE): waves do not run equally fast - the
+// workgroups a CU received first issue ahead of the later ones and get through a tile in 2.5 us where the last
+// ones need 3.9 - so equal shares leave the fast ones idle for the last fifth of the launch.
 struct rd_mf_pos {
     uint32_t tile, s, ti, inchunk;
 };
-__device__ __forceinline__ rd_mf_pos rd_mf_next(rd_mf_pos p, uint32_t chunk, uint32_t tps, uint32_t jump, uint32_t jq,
-                                                uint32_t jr) {
+// next_tile: first tile of the chunk that follows p's (>= total when there is none)
+struct rd_mf_nextchunk {
+    uint32_t tile, s, ti;  // first tile of the chunk that follows the current one (tile >= total: none), split
+};
+__device__ __forceinline__ rd_mf_nextchunk rd_mf_chunk_at(uint64_t chunk_id, uint32_t chunk, uint32_t tps, uint32_t total) {
+    rd_mf_nextchunk c;
+    const uint64_t nt = chunk_id * chunk;
+    c.tile = nt < total ? (uint32_t)nt : 0xFFFFFFFFu;
+    c.s = 0; c.ti = 0;
+    if (nt < total) {  // (the one division per chunk: done at the loop top, where few registers are live)
+        c.s = __builtin_amdgcn_readfirstlane(c.tile / tps);
+        c.ti = c.tile - c.s * tps;
+    }
+    return c;
+}
+__device__ __forceinline__ rd_mf_pos rd_mf_next(rd_mf_pos p, uint32_t chunk, uint32_t tps, const rd_mf_nextchunk &nc) {
     rd_mf_pos q;
     if (p.inchunk + 1 < chunk) {
         q.tile = p.tile + 1; q.inchunk = p.inchunk + 1;
         q.s = p.s; q.ti = p.ti + 1;
         if (q.ti >= tps) { q.ti = 0; q.s++; }
     } else {
-        q.tile = p.tile + jump; q.inchunk = 0;
-        q.s = p.s + jq; q.ti = p.ti + jr;
-        if (q.ti >= tps) { q.ti -= tps; q.s++; }
+        q.tile = nc.tile; q.inchunk = 0;
+        q.s = nc.s; q.ti = nc.ti;
     }
     return q;
 }
@@ -385,14 +401,24 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
     const uint32_t psel = h ? 0x07030602u : 0x05010400u;
 
     const uint32_t nwaves = gridDim.x * RD_MF_WAVES;
-    const uint32_t jump = (nwaves - 1) * chunk + 1;
-    const uint32_t jq = jump / tiles_per_stream, jr = jump % tiles_per_stream;
+    const uint32_t wave_id = blockIdx.x * RD_MF_WAVES + wave;
+    // RD_K1_STFLAGS & 4096: every wave takes chunks wave_id, wave_id + nwaves, ... (equal shares: A/B); the queue
+    // needs chunks of at least four tiles (the id of the following chunk is asked for in a chunk's first
+    // iteration, read in its second and first used in its last but one)
+    const bool dynamic = !(stflags & 4096) && chunk >= 4 && NBUF == 1;
+    uint32_t cur_chunk = wave_id;      // the chunk `cur` is in
+    rd_mf_nextchunk nextc = {0xFFFFFFFFu, 0, 0};
+    if (!dynamic) nextc = rd_mf_chunk_at((uint64_t)cur_chunk + nwaves, chunk, tiles_per_stream, total_tiles);
+    uint32_t grab = 0;                 // lane 0: what the atomic returned (valid one loop-top wait after its issue)
+    bool grab_pending = false;
+    const uint32_t my_queue = wave_id % RD_NQUEUE;
+    uint32_t *queue = &counters[RD_CNT_QUEUE0 + RD_QUEUE_STRIDE * my_queue];
     rd_mf_pos cur;
-    cur.tile = (blockIdx.x * RD_MF_WAVES + wave) * chunk;
+    cur.tile = wave_id * chunk;
     cur.s = cur.tile / tiles_per_stream;
     cur.ti = cur.tile % tiles_per_stream;
     cur.inchunk = 0;
-    rd_mf_pos nx1 = rd_mf_next(cur, chunk, tiles_per_stream, jump, jq, jr);
+    rd_mf_pos nx1 = rd_mf_next(cur, chunk, tiles_per_stream, nextc);
     uint32_t buf = 0;  // image buffer of the current tile (wave-uniform)
 
     uint32_t nst = 0;             // tiles staged (wave-uniform)
@@ -407,7 +433,25 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         // this tile has landed when at most the next tile's five loads are outstanding (vmcnt counts in
         // issue order; the previous iteration's word store and list flush are older or harmless)
         if (NBUF == 2 && nx1.tile < total_tiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(grab) : : "memory");
+        if (dynamic) {
+            if (grab_pending) {  // asked for one iteration ago: the wait above covers it
+                nextc = rd_mf_chunk_at((uint64_t)nwaves + my_queue + (uint64_t)RD_NQUEUE * __builtin_amdgcn_readfirstlane(grab),
+                                       chunk, tiles_per_stream, total_tiles);
+                grab_pending = false;
+            }
+            if (inchunk == 0) {  // a new chunk: ask for the one after it (inline asm: the compiler would wait for the result at once)
+                // lane 0 only, by way of the exec mask inside the statement (a branch around it costs 14 registers)
+                const uint32_t one = 1, zoff = 0;
+                uint64_t saved_exec;
+                asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                             : "+v"(grab), "=&s"(saved_exec) : "v"(zoff), "v"(one), "s"(queue) : "memory");
+                grab_pending = true;
+            }
+        } else if (inchunk == 0 && tile != wave_id * chunk) {  // equal shares: a new chunk was entered
+            cur_chunk += nwaves;
+            nextc = rd_mf_chunk_at((uint64_t)cur_chunk + nwaves, chunk, tiles_per_stream, total_tiles);
+        }
         // the short stretch from "data has landed" to "next loads issued" runs at raised priority: a wave whose
         // tile arrived should not queue behind three other waves' vector work before it can ask for the next
         if (!(stflags & 4)) __builtin_amdgcn_s_setprio(3);  // (RD_K1_STFLAGS & 4 switches it off: A/B)
@@ -422,7 +466,7 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         }
         if (rg_ptr) *rg_ptr = rg_word;
         rg_ptr = nullptr;
-        const rd_mf_pos nx2 = rd_mf_next(nx1, chunk, tiles_per_stream, jump, jq, jr);
+        const rd_mf_pos nx2 = rd_mf_next(nx1, chunk, tiles_per_stream, nextc);
         const rd_mf_pos fetch = NBUF == 2 ? nx2 : nx1;
         if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane);
         if (!(stflags & 4)) __builtin_amdgcn_s_setprio(0);
@@ -576,11 +620,12 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     }
     // (three workgroups per CU instead of the four that fit: within the run-to-run noise, +-2 %)
     const int per_cu = (per_cu_env >= 1 && per_cu_env <= 8) ? per_cu_env : per_cu_occ[variant];
-    // Tiles per chunk: a multiple of the 4-tile store groups.  Measured on 4096 x 132 tiles (two boxes, r02
-    // chunk sweep in DESIGN section 5): 28 is 4 % faster than 12 and than every other value between 8 and 66 -
-    // 12, 33, 44, 66 (whole numbers of rounds over the persistent waves) are the slow ones.  A small workload
-    // gets shorter chunks, down to one store group, until every resident wave has one.
-    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : 28;
+    // Tiles per chunk: a multiple of the 4-tile store groups.  With the work queues (default) 16: the chunks past a
+    // wave's first are handed out on demand, the waves that run faster take more of them, and shorter chunks
+    // even the finish out (0.459 ms; 28: 0.471, 12: 0.466, 8: 0.465 but a longer fix-up list).  With equal shares
+    // (RD_K1_STFLAGS & 4096) 28, the best of a sweep from 8 to 66 on 4096 x 132 tiles (profiles/r02_chunk_sweep.txt).
+    // A small workload gets shorter chunks, down to one store group, until every resident wave has one.
+    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : ((stflags & 4096) ? 28 : 16);
     if (chunk_env <= 0) {
         const uint64_t waves = (uint64_t)n_cu * per_cu * RD_MF_WAVES;
         while (chunk > RD_MF_STAGE_TILES && total64 / chunk < waves) chunk -= RD_MF_STAGE_TILES;
@@ -637,8 +682,8 @@ extern "C" int rd_debug_demod_mfma(const uint8_t *iq_host, int n_streams, uint32
     RD_DBG_CHK(hipMalloc(&d_bits, words * n_streams * 4));
     RD_DBG_CHK(hipMemset(d_bits, 0, words * n_streams * 4));
     RD_DBG_CHK(hipMalloc(&d_fix, (size_t)fix_cap * 4 + 4));
-    RD_DBG_CHK(hipMalloc(&d_cnt, RD_CNT_SLOTS * 4));
-    RD_DBG_CHK(hipMemset(d_cnt, 0, RD_CNT_SLOTS * 4));
+    RD_DBG_CHK(hipMalloc(&d_cnt, RD_CNT_TOTAL * 4));
+    RD_DBG_CHK(hipMemset(d_cnt, 0, RD_CNT_TOTAL * 4));
     RD_DBG_CHK(hipMalloc(&d_g, g_floats * 4));
     RD_DBG_CHK(hipMemset(d_g, 0, g_floats * 4));
     {

@@ -9,6 +9,13 @@
 // FIX: flagged runs; MATCH: preamble matches (= primary records); REC: second records of
 // block-boundary positions; PARSED: CRC-valid messages
 enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
+// Behind the RD_CNT_SLOTS counters the host reads back: the demod kernel's work queues (chunks handed out beyond
+// the first one of every wave).  One counter word sustains ~90 atomics per microsecond, so there are RD_NQUEUE of
+// them, 256 bytes apart; wave w draws from queue w % RD_NQUEUE, which owns the chunks nwaves + q + RD_NQUEUE k.
+#define RD_NQUEUE 32
+#define RD_QUEUE_STRIDE 64                                     /* words */
+#define RD_CNT_QUEUE0 RD_QUEUE_STRIDE                          /* first queue's word index */
+#define RD_CNT_TOTAL (RD_CNT_QUEUE0 + RD_NQUEUE * RD_QUEUE_STRIDE)  /* words per counter set */
 
 // Geometry of the fused demod kernel
 #define RD_TILE_SAMPLES 2048  // 64 lanes x 32 samples: one wave iteration
@@ -52,7 +59,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
-// zero_next (may be null): RD_CNT_SLOTS counters to clear for the handle's next run.
+// zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
                      uint32_t *zero_next, hipStream_t st);
 // Search positions p in [p_lo, p_hi] of every stream's bit array (bits outside [0, n_bits) are 0).

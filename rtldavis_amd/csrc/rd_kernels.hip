@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
                                                uint32_t fix_cap, const uint32_t *counters, int all,
                                                uint32_t *zero_next) {
     // the counters of the handle's NEXT run (double-buffered) are cleared here, saving a memset launch
-    if (zero_next && blockIdx.x == 0 && threadIdx.x < RD_CNT_SLOTS) zero_next[threadIdx.x] = 0;
+    if (zero_next && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < RD_CNT_TOTAL; i += blockDim.x) zero_next[i] = 0;
     uint64_t count;
     if (all) {
         count = (uint64_t)lay.n_streams * runs_per_stream;
