@@ -36,7 +36,7 @@ python3 $ROOT/tools/profile_collect.py traffic $OUT $COMMIT > $OUT/traffic.json
 cat $OUT/traffic.json | tee -a $OUT/progress.log
 
 step "5/8 ablations of the demod kernel (tools/k1_ab.py)"
-timeout -k 10 500 python3 $ROOT/tools/k1_ab.py --key all mfma valu=RD_K1_IMPL=valu no_guard=RD_K1_DEBUG=7 compute_only=RD_K1_DEBUG=1 no_mfma=RD_K1_DEBUG=4 mfma_only=RD_K1_DEBUG=5 loads_stores_only=RD_K1_DEBUG=2 loads_only=RD_K1_DEBUG=6 two_buffers=RD_K1_NBUF=2 wgs3=RD_K1_WGS_PER_CU=3 wgs2=RD_K1_WGS_PER_CU=2 no_prio=RD_K1_STFLAGS=4 chunk12=RD_K1_CHUNK=12 chunk20=RD_K1_CHUNK=20 chunk36=RD_K1_CHUNK=36 chunk60=RD_K1_CHUNK=60 > $OUT/ablation.txt 2>&1
+timeout -k 10 500 python3 $ROOT/tools/k1_ab.py --key all mfma valu=RD_K1_IMPL=valu no_guard=RD_K1_DEBUG=7 compute_only=RD_K1_DEBUG=1 no_mfma=RD_K1_DEBUG=4 mfma_only=RD_K1_DEBUG=5 loads_stores_only=RD_K1_DEBUG=2 loads_only=RD_K1_DEBUG=6 two_buffers=RD_K1_NBUF=2 wgs3=RD_K1_WGS_PER_CU=3 wgs2=RD_K1_WGS_PER_CU=2 no_prio=RD_K1_STFLAGS=4 equal_shares28=RD_K1_STFLAGS=4096 equal_shares12=RD_K1_STFLAGS=4096,RD_K1_CHUNK=12 chunk8=RD_K1_CHUNK=8 chunk28=RD_K1_CHUNK=28 > $OUT/ablation.txt 2>&1
 cat $OUT/ablation.txt | tee -a $OUT/progress.log
 
 step "6/8 wideband (channelizer) line and its kernel stats"
