@@ -300,6 +300,9 @@ def main():
     # come back (profiles/r02_clock_settle.txt).  A step is 0.65 ms, so W = 5 warmup steps end long before that and
     # a short timed region would measure the ramp, not the path.  The settle phase is untimed, disclosed in the
     # output line, and the same steps as everything else; the K timed steps follow the W warmup steps unchanged.
+    import gc
+    gc.collect()
+    gc.disable()  # no collection pause of the interpreter inside the 60 ms timed region (nor an idle GPU right before it)
     settle_steps, settle_s = 0, 0.0
     if args.settle > 0:
         ts = time.perf_counter()
@@ -316,6 +319,7 @@ def main():
     recs, bd = run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     tms = [x.timing() for x in bds]  # mean kernel durations (HIP events on the launch stream)
     assert sum(t["runs"] for t in tms) == args.steps
     tm = {k: sum(t[k] * t["runs"] for t in tms) / args.steps for k in tms[0] if k != "runs"}

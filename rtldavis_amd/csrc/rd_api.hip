@@ -618,6 +618,16 @@ extern "C" int rd_batch_set_timing(rd_batch *b, int enabled) {
     b->timing = enabled != 0;
     b->timing_detail = enabled >= 2;  // 1: demod kernel and total only (3 events per run); 2: every stage
     b->ev_runs = 0;
+    // events for the first 64 timed runs exist before the first of them is launched (creating them one run at a
+    // time showed as a stall of several milliseconds inside a 60 ms timed region)
+    if (b->timing && b->dev_ready && use_device(b->device) == RD_OK) {
+        const size_t want = 5 * 64;
+        const size_t old = b->evs.size();
+        if (old < want) {
+            b->evs.resize(want, nullptr);
+            for (size_t i = old; i < want; i++) HIPCHK(hipEventCreate(&b->evs[i]));
+        }
+    }
     return RD_OK;
 }
 
