@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of back-to-back steps after the timed region (reported separately; 0 = off)")
     ap.add_argument("--two-streams", action="store_true", help="one HIP stream per resident batch")
+    ap.add_argument("--step-times", action="store_true", help="diagnostic: print the slowest steps' host times to stderr")
     ap.add_argument("--resident", type=int, default=2,
                     help="resident copies of the batch demodulated round-robin (>= 2): runs queued ahead of the host; "
                          "3 and 4 measured no better than 2 (profiles/r02_readback_sdma.txt)")
@@ -274,6 +275,7 @@ def main():
     # kernels idles the GPU for ~6 us, so the per-stage split is opt-in and comes from rocprofv3)
 
     R = len(bds)
+    step_log = [] if args.step_times else None  # diagnostic: host time of run() and results() per step
 
     def run_steps(k):
         """k full steps; step i = bds[i % R].run + its results().  R resident copies of the batch are
@@ -285,9 +287,13 @@ def main():
             bds[i % R].run(streams[i % R])
         for i in range(k):
             nxt = i + R - 1
+            ta = time.perf_counter() if step_log is not None else 0.0
             if nxt < k:
                 bds[nxt % R].run(streams[nxt % R])
+            tb = time.perf_counter() if step_log is not None else 0.0
             recs = bds[i % R].results()
+            if step_log is not None:
+                step_log.append((tb - ta, time.perf_counter() - tb))
         return recs, bds[(k - 1) % R]
 
     def sync_all():
@@ -320,6 +326,13 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if step_log is not None and rank == 0:
+        timed = step_log[-args.steps:]
+        worst = sorted(range(len(timed)), key=lambda j: -(timed[j][0] + timed[j][1]))[:6]
+        print("step times (ms): median run %.3f results %.3f; slowest: %s" % (
+            1e3 * sorted(t[0] for t in timed)[len(timed) // 2], 1e3 * sorted(t[1] for t in timed)[len(timed) // 2],
+            ", ".join("#%d run %.2f results %.2f" % (j, 1e3 * timed[j][0], 1e3 * timed[j][1]) for j in worst)), file=sys.stderr)
+        del step_log[:]
     tms = [x.timing() for x in bds]  # mean kernel durations (HIP events on the launch stream)
     assert sum(t["runs"] for t in tms) == args.steps
     tm = {k: sum(t[k] * t["runs"] for t in tms) / args.steps for k in tms[0] if k != "runs"}
