@@ -248,6 +248,7 @@ struct rd_batch {
     uint32_t *d_bits = nullptr, *d_fix = nullptr, *d_cnt = nullptr;
     rd_match *d_matches = nullptr;
     void *d_tasks = nullptr;         // rec_cap entries of RD_TASK_BYTES (two-kernel slice)
+    int dense = 0;                   // the last run's records are dense (one per task from index 0)
     rd_packet *d_recs = nullptr;     // rec_cap = 2 * match_cap entries (layout: rd_launch_slice)
     int cnt_set = 0;                 // d_cnt holds two counter sets; a run's fixup kernel clears the other one
     bool parse = false;              // Parser.parse front half on the device (rd_batch_set_parse)
@@ -391,11 +392,12 @@ static int batch_search_slice(rd_batch *b, hipStream_t st) {
     // the run's last kernel carries the end-of-run event itself when nothing follows it
     hipEvent_t last = b->run_timing ? b->ev[4] : b->kdone;
     const bool last_on_slice = !b->parse;
-    rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1, b->n_blocks, 0,
-                    b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr, b->d_tasks);
+    b->dense = rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1,
+                               b->n_blocks, 0, b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr,
+                               b->d_tasks);
     if (b->parse) {
         if (!b->d_parsed) HIPCHK(hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed)));
-        rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st);
+        rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st, b->dense);
     }
     // results come back with the run: counters plus as many records as the last run produced
     // (+25 %); rd_batch_results fetches the remainder if this run produced more.
@@ -512,8 +514,9 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     const double t1 = now_ms();
     // one record per match, plus the second records of block-boundary positions (kept apart on
     // the device, appended here)
-    const uint32_t nprim = std::min(b->h_cnt[RD_CNT_MATCH], b->match_cap);
-    const uint32_t nextra = std::min(b->h_cnt[RD_CNT_REC], b->match_cap);
+    // sparse layout: one slot per match + the block-boundary twins behind match_cap; dense: one record per task
+    const uint32_t nprim = b->dense ? std::min(b->h_cnt[RD_CNT_TASKS], b->rec_cap) : std::min(b->h_cnt[RD_CNT_MATCH], b->match_cap);
+    const uint32_t nextra = b->dense ? 0u : std::min(b->h_cnt[RD_CNT_REC], b->match_cap);
     const uint32_t have = std::min(b->match_cap, b->spec_recs);
     // Late copies go to the copy stream: it has already waited for this run's last kernel, whereas the
     // launch stream may hold the NEXT batch's run by now (two resident batches alternate in bench.py) and a

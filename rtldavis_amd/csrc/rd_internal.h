@@ -75,7 +75,8 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 // left to the host, which orders the records anyway.  recs (device memory) and recs_host (the
 // device address of pinned, mapped host memory) are both optional: the kernel stores to each that
 // is given; with recs_host the records need no device-to-host copy.
-void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
+// returns 1 when the records were written densely (one per task, RD_CNT_TASKS of them from index 0), else 0
+int rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
                      const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
                      rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st,
                      hipEvent_t ev_stop = nullptr, void *tasks = nullptr);
@@ -84,7 +85,7 @@ void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_str
 // Parser.parse front half (protocol.py:290-311) over the records of a batch run (layout as
 // above): CRC-valid ones are written to `parsed` (RD_CNT_PARSED) with their frequency error.
 void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,
-                     rd_parsed *parsed, uint32_t *counters, hipStream_t st);
+                     rd_parsed *parsed, uint32_t *counters, hipStream_t st, int dense = 0);
 // d[t0 .. t0+n) of stream `stream` in float64
 void rd_launch_disc(const rd_layout &lay, int stream, long t0, long n, double *out, hipStream_t st);
 // f[t0 .. t0+n) (interleaved re,im) of stream `stream` in float64

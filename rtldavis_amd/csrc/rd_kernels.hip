@@ -1030,8 +1030,7 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *bits, size_t b
             return (same_prev && q >= 1 && prev_first) || (same_next && q + 1 <= cfg.B && next_first);
         };
         const bool use0 = ok0 && !superseded(q0), use1 = ok1 && !superseded(q1);
-        const int ntask = (use0 ? 1 : 0) + (use1 ? 1 : 0);
-        if (live && ntask == 0) recs[i].stream = -1;
+        const int ntask = (use0 ? 1 : 0) + (use1 ? 1 : 0);  // records of this match: task t owns record t (dense)
         // task slots: ONE atomic per workgroup and trip (a counter word sustains ~90 atomics per microsecond: one per
         // wave was 12 of this kernel's 20 us).  All waves of a workgroup make the same number of trips.
         const uint32_t incl = rd_wave_incl_scan_u32((uint32_t)ntask, lane);
@@ -1067,11 +1066,8 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t *bits, size_t b
                 const rd_task tk = {ri, stream, call, q};
                 tasks[t++] = tk;
             };
-            put(i, pb, pq);
-            if (use0 && use1) {
-                const uint32_t xslot = atomicAdd(&counters[RD_CNT_REC], 1u);  // rare: a position on a block boundary
-                put(match_cap + xslot, b1, q1);
-            }
+            put(t, pb, pq);
+            if (use0 && use1) put(t, b1, q1);  // a position on a block boundary: reported by both calls
         }
     }
 }
@@ -1144,10 +1140,10 @@ static uint32_t rd_slice_grid(uint32_t match_cap) {
     return wgs ? wgs : 1;
 }
 
-void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
-                     const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
-                     rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop,
-                     void *tasks) {
+int rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, const rd_devcfg &cfg,
+                    const rd_match *matches, uint32_t match_cap, int batch_mode, int n_calls, int call,
+                    rd_packet *recs, rd_packet *recs_host, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop,
+                    void *tasks) {
     rd_u8_src src;
     src.lay = lay;
     static int two = -1;
@@ -1166,7 +1162,7 @@ void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_str
         else
             hipLaunchKernelGGL(k_rssi_u8, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_task *)tasks,
                                2 * match_cap, recs, counters);
-        return;
+        return 1;  // records: one per task, dense from index 0 (RD_CNT_TASKS of them)
     }
     if (ev_stop)  // the dispatch records the event itself (no marker packet behind the kernel)
         hipExtLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, nullptr,
@@ -1176,6 +1172,7 @@ void rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_str
         hipLaunchKernelGGL(k_slice_rssi<rd_u8_src>, dim3(rd_slice_grid(match_cap)), dim3(256), 0, st, src, bits,
                            bits_stride, (n_bits + 31) / 32, cfg, matches, match_cap, batch_mode, n_calls, call, recs,
                            recs_host, counters);
+    return 0;  // records: one slot per match (RD_CNT_MATCH, void ones marked) + the block-boundary twins behind match_cap
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1193,19 +1190,24 @@ __device__ __forceinline__ uint32_t rd_swap_bits8(uint32_t b) {  // protocol.py:
 }
 
 __global__ __launch_bounds__(256) void k_parse_select(const rd_packet *recs, uint32_t match_cap, rd_parsed *parsed,
-                                                      uint32_t *counters) {
+                                                      uint32_t *counters, int dense) {
     // records: [0, matches) one per match (stream < 0: reported by no call) and
     // [match_cap, match_cap + RD_CNT_REC) the second records of block-boundary positions
     uint32_t nprim = counters[RD_CNT_MATCH], nextra = counters[RD_CNT_REC];
     if (nprim > match_cap) nprim = match_cap;
     if (nextra > match_cap) nextra = match_cap;
+    if (dense) {  // the two-kernel slice writes one record per task, densely, from index 0
+        nprim = counters[RD_CNT_TASKS];
+        if (nprim > 2 * match_cap) nprim = 2 * match_cap;
+        nextra = 0;
+    }
     const uint32_t rec_cap = 2 * match_cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool ok = false;
     uint8_t sw[RD_MAX_PKT_BYTES];
     int nb = 0;
-    if ((i < nprim || (i >= match_cap && i - match_cap < nextra)) && recs[i].stream >= 0) {
+    if ((i < nprim || (!dense && i >= match_cap && i - match_cap < nextra)) && recs[i].stream >= 0) {
         const rd_packet *r = &recs[i];
         nb = r->nbytes;
         uint32_t crc = 0;
@@ -1269,10 +1271,10 @@ __global__ __launch_bounds__(256) void k_freq_err(rd_layout lay, rd_devcfg cfg, 
 }
 
 void rd_launch_parse(const rd_layout &lay, const rd_devcfg &cfg, const rd_packet *recs, uint32_t match_cap,
-                     rd_parsed *parsed, uint32_t *counters, hipStream_t st) {
+                     rd_parsed *parsed, uint32_t *counters, hipStream_t st, int dense) {
     const uint32_t rec_cap = 2 * match_cap;
     hipLaunchKernelGGL(k_parse_select, dim3((rec_cap + 255) / 256), dim3(256), 0, st, recs, match_cap, parsed,
-                       counters);
+                       counters, dense);
     uint32_t wgs = (rec_cap + 3) / 4;
     if (wgs > 2048) wgs = 2048;
     hipLaunchKernelGGL(k_freq_err, dim3(wgs), dim3(256), 0, st, lay, cfg, parsed, rec_cap, counters);
