@@ -767,3 +767,36 @@ def test_batch_discriminated_whole_streams_against_c_oracle(dsp, batchmod):
         worst = max(worst, float(err.max()))
         assert np.all(err <= 1e-5), f"stream {i}: {err.max()} at {int(err.argmax())}"
     assert worst < 1e-5
+
+
+def test_slice_forms_agree(dsp, batchmod, tmp_path):
+    """The two-kernel slice of the batch path (k_classify + k_rssi_u8: dense records, RSSI windows on the matrix pipe)
+    and the one-kernel form (RD_SLICE_IMPL=wave, read once per process: hence the child) return the same packets;
+    RSSI and SNR agree to 1e-3 dB (the fixtures' tolerance: fp32 window sums against the exact integer filter)."""
+    import subprocess
+    import sys
+    seeds = list(range(24))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    bd.upload(raw)
+    bd.run()
+    mine = bd.results().copy()
+    out = tmp_path / "wave.npy"
+    child = (
+        "import sys, numpy as np\n"
+        "from rtldavis_amd import batch, dsp, synth\n"
+        "cfg = dsp.PacketConfig(19200, 14, 16, 80, '1100101110001001', 8192)\n"
+        f"raw = synth.synth_streams(list(range({len(seeds)})))\n"
+        f"bd = batch.BatchDemodulator(cfg, {len(seeds)}, synth.BLOCKS_PER_STREAM)\n"
+        "bd.upload(raw); bd.run()\n"
+        f"np.save(r'{out}', bd.results())\n")
+    env = dict(os.environ, RD_SLICE_IMPL="wave")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", child], check=True, env=env, cwd=root, timeout=300)
+    other = np.load(out)
+    assert len(mine) == len(other) > 0
+    for f in ("stream", "call", "index", "nbytes"):
+        assert np.array_equal(mine[f], other[f]), f
+    assert np.array_equal(mine["data"], other["data"])
+    assert np.all(np.abs(mine["rssi"] - other["rssi"]) < 1e-3)
+    assert np.all(np.abs(mine["snr"] - other["snr"]) < 1e-3)
