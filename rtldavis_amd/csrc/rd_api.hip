@@ -162,10 +162,17 @@ static int make_devcfg(const rd_config *c, rd_devcfg *d) {
 // lists: the key is packed into 64 bits (when the field widths allow) and sorted with LSD
 // counting passes over (key, index) pairs - a comparison sort that moves 64-byte records costs
 // tens of milliseconds at 7e4 records.  `recs` may be pinned memory; output goes to `out`.
-static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector<rd_packet> &out) {
-    out.clear();
+struct rd_order_scratch {  // kept per handle: no allocation per call once warm
+    std::vector<uint32_t> idx, itmp, kept;
+    std::vector<uint64_t> key, ktmp;
+};
+
+// Fills sc.kept with the indices of the records to return, in order.
+static void order_and_dedupe(const rd_packet *recs, size_t n, int S, rd_order_scratch &sc) {
+    std::vector<uint32_t> &idx = sc.idx, &kept = sc.kept;
+    kept.clear();
+    idx.clear();
     if (n == 0) return;
-    std::vector<uint32_t> idx;
     idx.reserve(n);
     for (size_t i = 0; i < n; i++)
         if (recs[i].stream >= 0) idx.push_back((uint32_t)i);  // stream < 0: match reported by no call
@@ -194,21 +201,24 @@ static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector
         const int bi = bits_for(max_index), bp = bits_for((uint32_t)(S - 1)), bc = bits_for(max_call),
                   bs = bits_for(max_stream);
         if (bi + bp + bc + bs <= 64) {
-            std::vector<uint64_t> key(n), ktmp(n);
-            std::vector<uint32_t> itmp(n);
+            std::vector<uint64_t> &key = sc.key, &ktmp = sc.ktmp;
+            std::vector<uint32_t> &itmp = sc.itmp;
+            key.resize(n); ktmp.resize(n); itmp.resize(n);
             for (size_t i = 0; i < n; i++) {
                 const rd_packet &r = recs[idx[i]];
                 key[i] = ((((uint64_t)(uint32_t)r.stream << bc | (uint32_t)r.call) << bp | (uint32_t)(r.index % S)) << bi) |
                          (uint32_t)r.index;
             }
+            // LSD passes of 12 bits (the bench shape's 36-bit key: three)
             const int total_bits = bi + bp + bc + bs;
-            uint32_t count[2049];
-            for (int shift = 0; shift < total_bits; shift += 11) {
+            constexpr int DB = 12;
+            static thread_local uint32_t count[(1 << DB) + 1];
+            for (int shift = 0; shift < total_bits; shift += DB) {
                 memset(count, 0, sizeof count);
-                for (size_t i = 0; i < n; i++) count[((key[i] >> shift) & 2047) + 1]++;
-                for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+                for (size_t i = 0; i < n; i++) count[((key[i] >> shift) & ((1u << DB) - 1)) + 1]++;
+                for (int d = 0; d < (1 << DB); d++) count[d + 1] += count[d];
                 for (size_t i = 0; i < n; i++) {
-                    const uint32_t pos = count[(key[i] >> shift) & 2047]++;
+                    const uint32_t pos = count[(key[i] >> shift) & ((1u << DB) - 1)]++;
                     ktmp[pos] = key[i];
                     itmp[pos] = idx[i];
                 }
@@ -219,14 +229,15 @@ static void order_and_dedupe(const rd_packet *recs, size_t n, int S, std::vector
             std::sort(idx.begin(), idx.end(), less);
         }
     }
-    out.reserve(n);
+    // per-call dedupe (py:203-205): the first occurrence of a byte string inside (stream, call) wins
+    kept.reserve(n);
     size_t group = 0;
     for (size_t i = 0; i < n; i++) {
         const rd_packet &r = recs[idx[i]];
-        if (out.empty() || r.stream != out.back().stream || r.call != out.back().call) group = out.size();
+        if (kept.empty() || r.stream != recs[kept.back()].stream || r.call != recs[kept.back()].call) group = kept.size();
         bool dup = false;
-        for (size_t k = group; k < out.size() && !dup; k++) dup = memcmp(out[k].data, r.data, (size_t)r.nbytes) == 0;
-        if (!dup) out.push_back(r);
+        for (size_t k = group; k < kept.size() && !dup; k++) dup = memcmp(recs[kept[k]].data, r.data, (size_t)r.nbytes) == 0;
+        if (!dup) kept.push_back(idx[i]);
     }
 }
 
@@ -249,6 +260,7 @@ struct rd_batch {
     rd_match *d_matches = nullptr;
     void *d_tasks = nullptr;         // rec_cap entries of RD_TASK_BYTES (two-kernel slice)
     int dense = 0;                   // the last run's records are dense (one per task from index 0)
+    rd_order_scratch order;          // host ordering scratch
     rd_packet *d_recs = nullptr;     // rec_cap = 2 * match_cap entries (layout: rd_launch_slice)
     int cnt_set = 0;                 // d_cnt holds two counter sets; a run's fixup kernel clears the other one
     bool parse = false;              // Parser.parse front half on the device (rd_batch_set_parse)
@@ -531,18 +543,18 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     }
     const uint32_t nrec = nprim + nextra;
     b->spec_recs = std::max<uint32_t>(1024, nprim + nprim / 4);
-    std::vector<rd_packet> recs;
     const double t2 = now_ms();
-    order_and_dedupe(b->h_recs_pin, nrec, b->dc.S, recs);
-    if (dbg_host())
-        fprintf(stderr, "[rd] results: finish %.3f ms, D2H %u recs %.3f ms, order+dedupe %.3f ms\n", t1 - t0, nrec,
-                t2 - t1, now_ms() - t2);
-    *n = (int)recs.size();
-    if ((int)recs.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", recs.size());
-    if (!recs.empty()) {
+    order_and_dedupe(b->h_recs_pin, nrec, b->dc.S, b->order);
+    const std::vector<uint32_t> &kept = b->order.kept;
+    *n = (int)kept.size();
+    if ((int)kept.size() > cap) return fail(RD_ERR_CAPACITY, "need room for %zu packets", kept.size());
+    if (!kept.empty()) {
         if (!out) return fail(RD_ERR_ARG, "null out");
-        memcpy(out, recs.data(), recs.size() * sizeof(rd_packet));
+        for (size_t i = 0; i < kept.size(); i++) out[i] = b->h_recs_pin[kept[i]];  // straight into the caller's array
     }
+    if (dbg_host())
+        fprintf(stderr, "[rd] results: finish %.3f ms, D2H %u recs %.3f ms, order+dedupe+copy %.3f ms\n", t1 - t0, nrec,
+                t2 - t1, now_ms() - t2);
     return RD_OK;
 }
 
@@ -712,6 +724,7 @@ struct rd_demod {
     int head = 0, nflight = 0;      // oldest block in flight, blocks in flight (0..2)
     hipStream_t st = nullptr, st_copy = nullptr;
     std::vector<rd_packet> last;    // ordered, deduplicated records of the last fetched block
+    rd_order_scratch order;         // host ordering scratch
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     bool fast_ok = false;
 };
@@ -960,7 +973,9 @@ static int demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {
     h->head ^= 1;
     h->nflight--;
     const uint32_t nrec = std::min(sl.h_cnt[RD_CNT_MATCH], h->match_cap);  // one record per match (no call overlap here)
-    order_and_dedupe(sl.h_recs, nrec, h->dc.S, h->last);
+    order_and_dedupe(sl.h_recs, nrec, h->dc.S, h->order);
+    h->last.clear();
+    for (uint32_t k : h->order.kept) h->last.push_back(sl.h_recs[k]);
     return demod_give(h, out, cap, n);
 }
 
