@@ -338,6 +338,12 @@ static int batch_alloc(rd_batch *b) {
     b->fix_cap = (uint32_t)std::min<uint64_t>(runs, std::max<uint64_t>(4096, runs / 8));
     // ~16 raw matches per 33-block stream on noise + one burst; the lists grow on overflow
     b->match_cap = (uint32_t)std::min<uint64_t>((uint64_t)b->n_streams * (8 + 1ull * b->n_blocks) + 1024, 1u << 26);
+    // test hook: a deliberately small first list so that the overflow path (grow, search and slice again) runs on
+    // ordinary inputs (tests/test_gpu_parity.py::test_match_list_overflow_is_transparent)
+    if (const char *e = getenv("RD_TEST_MATCH_CAP")) {
+        const long v = atol(e);
+        if (v >= 1 && v < (long)b->match_cap) b->match_cap = (uint32_t)v;
+    }
     b->rec_cap = 2 * b->match_cap;
     HIPCHK(hipMalloc(&b->d_iq, b->iq_bytes + RD_INPUT_PAD));
     HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));

@@ -800,3 +800,18 @@ def test_slice_forms_agree(dsp, batchmod, tmp_path):
     assert np.array_equal(mine["data"], other["data"])
     assert np.all(np.abs(mine["rssi"] - other["rssi"]) < 1e-3)
     assert np.all(np.abs(mine["snr"] - other["snr"]) < 1e-3)
+
+
+def test_match_list_overflow_is_transparent(dsp, batchmod, golden_streams, monkeypatch):
+    """A first match list that is far too small (RD_TEST_MATCH_CAP, read when the handle allocates): the run's
+    counters say so, rd_batch_results grows the lists, searches and slices again, and the packets are the
+    fixtures' - for the dense (two-kernel) record layout of the production shape and twice in a row."""
+    monkeypatch.setenv("RD_TEST_MATCH_CAP", "7")
+    seeds = list(range(12))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    for _ in range(2):
+        res = bd.demodulate(raw)
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+    assert bd.counters()["matches"] > 7
