@@ -110,6 +110,11 @@ def soak_bursts(n_streams, seed, verbose=True):
         got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
         exp = [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
         assert got == exp, (i, got, exp)
+        # RSSI / SNR of every packet against the oracle's float64 windows (1e-3 dB): the batch path evaluates them on
+        # the matrix pipe, windows that reach the end of the stream on its fp32 path
+        flat = [p for ps in res[i] for p in ps]
+        for a, b in zip(flat, want[i]):
+            assert abs(a.rssi - b.rssi) < 1e-3 and abs(a.snr - b.snr) < 1e-3, (i, a, b)
         twice += sum(1 for g in got if g[1] == B)
         n += len(got)
     for i in range(min(n_streams, 24)):
