@@ -4,7 +4,8 @@ matches -> 10-byte packets with RSSI/SNR) on synthetic Davis streams, per BASELI
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (launched by torch.distributed.run for N > 1).  Streams are
+One process per GPU: for N > 1 either under a launcher (torch.distributed.run sets RANK / WORLD_SIZE) or plainly as
+`python bench.py --gpus N`, which starts the N ranks itself (launch_ranks).  Streams are
 independent, so each rank demodulates its own shard and no collective touches the data
 path (weak scaling: 4096 streams per GPU, BASELINE.json configs[3] / configs[4]).  A
 step = one full pass over the rank's resident batch: rd_batch_run (all kernels) followed by
@@ -54,8 +55,9 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=33, help="8192-sample blocks per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--sustain", type=float, default=2.0,
-                    help="seconds of back-to-back steps after the timed region (reported separately; 0 = off)")
+    ap.add_argument("--sustain", type=float, default=6.0,
+                    help="seconds of back-to-back steps after the timed region (reported separately, never `value`; "
+                         "0 = off).  Longer than a 5 s utilisation sampler's period, so that one cannot miss the GPU work")
     ap.add_argument("--two-streams", action="store_true", help="one HIP stream per resident batch")
     ap.add_argument("--step-times", action="store_true", help="diagnostic: print the slowest steps' host times to stderr")
     ap.add_argument("--resident", type=int, default=2,
@@ -207,16 +209,37 @@ def wideband(args):
                   "(<= 1 LSB) and by recovering the injected packets through the pinned demodulator"}), flush=True)
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1) and hand back their exit code.  This parent process never
+    touches the GPU (no HIP call, no torch import) and never exec()s: the ranks are ordinary children, rank 0's
+    JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this platform (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        return subprocess.run(cmd, env=env).returncode
+    except KeyboardInterrupt:
+        return 130
+
+
 def main():
     args = parse_args()
     if args.wideband:
         return wideband(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
     import torch
@@ -440,6 +463,9 @@ def main():
         if sustained:
             out["sustained"] = sustained
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+            # the GPU figures are complete here: show them (stderr) before the CPU legs take their ~25 s; the ONE JSON
+            # line on stdout follows with `cpu_baseline` in it
+            print("bench.py: GPU part done, CPU baseline legs running: " + json.dumps(out), file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline(uniq)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -13,4 +13,19 @@ import os as _os
 # 4 MB readback took 420 us instead of 97 and slowed that kernel by 7 %; whole-step throughput +10 %
 # with the SDMA path, profiles/r02_readback_sdma.txt).  Read by the HIP runtime when it initialises,
 # so it has to be in the environment before the first HIP call of the process; an explicit setting wins.
-_os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "0")
+if "GPU_FORCE_BLIT_COPY_SIZE" not in _os.environ:
+    _os.environ["GPU_FORCE_BLIT_COPY_SIZE"] = "0"
+    # Too late when something in this process has initialised HIP already (torch.cuda does on first use): the
+    # runtime has read its flags by then and the setting silently does nothing.  Say so once.
+    import sys as _sys
+    _torch = _sys.modules.get("torch")
+    try:
+        _late = bool(_torch is not None and _torch.cuda.is_initialized())
+    except Exception:  # noqa: BLE001
+        _late = False
+    if _late:
+        import warnings as _warnings
+        _warnings.warn("rtldavis_amd: HIP was initialised before this import, so GPU_FORCE_BLIT_COPY_SIZE=0 cannot take "
+                       "effect: device-to-host copies of the packet records will run as blit kernels beside the demod "
+                       "kernel (about 10 % less batch throughput).  Import rtldavis_amd first, or export "
+                       "GPU_FORCE_BLIT_COPY_SIZE=0 in the environment.", RuntimeWarning, stacklevel=2)

@@ -499,16 +499,27 @@ static int batch_finish(rd_batch *b) {
             b->last_fix = b->h_cnt[RD_CNT_FIX];
         }
         if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
-            hipFree(b->d_matches); hipFree(b->d_recs); hipHostFree(b->h_recs_pin);
+            // every pointer is cleared as it is freed: should one of the allocations below fail, rd_batch_destroy
+            // must not free anything twice (and the handle reports the failure on every later call)
+            hipFree(b->d_matches); b->d_matches = nullptr;
+            hipFree(b->d_recs); b->d_recs = nullptr;
+            hipHostFree(b->h_recs_pin); b->h_recs_pin = nullptr;
+            b->rec_pin_cap = 0;
             hipFree(b->d_tasks); b->d_tasks = nullptr;
             hipFree(b->d_parsed); b->d_parsed = nullptr;
-            b->match_cap = b->h_cnt[RD_CNT_MATCH] + b->h_cnt[RD_CNT_MATCH] / 4 + 1024;
-            b->rec_cap = 2 * b->match_cap;
-            HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
-            HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
-            HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
-            HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)b->rec_cap * sizeof(rd_packet), hipHostMallocDefault));
-            b->rec_pin_cap = b->rec_cap;
+            const uint32_t want = b->h_cnt[RD_CNT_MATCH] + b->h_cnt[RD_CNT_MATCH] / 4 + 1024;
+            b->match_cap = 0;  // until the new lists exist
+            b->rec_cap = 0;
+            b->ran = false;    // a failed re-allocation leaves a handle that must be run again
+            const uint32_t new_rec_cap = 2 * want;
+            HIPCHK(hipMalloc(&b->d_matches, (size_t)want * sizeof(rd_match)));
+            HIPCHK(hipMalloc(&b->d_recs, (size_t)new_rec_cap * sizeof(rd_packet)));
+            HIPCHK(hipMalloc(&b->d_tasks, (size_t)new_rec_cap * RD_TASK_BYTES));
+            HIPCHK(hipHostMalloc((void **)&b->h_recs_pin, (size_t)new_rec_cap * sizeof(rd_packet), hipHostMallocDefault));
+            b->match_cap = want;
+            b->rec_cap = new_rec_cap;
+            b->rec_pin_cap = new_rec_cap;
+            b->ran = true;
             redo_search = true;
         }
         if (!redo_search) {

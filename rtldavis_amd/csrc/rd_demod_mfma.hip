@@ -16,6 +16,7 @@
 // buffer.  A wave works through `chunk` consecutive tiles so that the very first group of a tile finds
 // its predecessors in the previous iteration; at the start of a chunk (and of a stream) that one
 // group is put on the fix-up list instead.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -27,6 +28,9 @@
 
 #define RD_MF_WG 256
 #define RD_MF_WAVES (RD_MF_WG / 64)
+#ifndef RD_MF_MINWAVES
+#define RD_MF_MINWAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#endif
 // LDS image of a tile, wave-private: [16 B: the chunk before the tile][4 groups of 72 slots]; group i
 // holds the 64 chunks (16 B) of columns 8i..8i+7, chunk e of column n' at slot n' + 8 e.  One
 // global_load_lds_dwordx4 fills a group (lane l supplies source chunk 8 (l & 7) + (l >> 3): a
@@ -132,12 +136,15 @@ struct rd_mf_state {
 // hand (v_max3 over the block) and the test repeated with it.
 __device__ __forceinline__ bool rd_mf_any(bool c) { return __ballot(c) != 0; }
 
-// One 16-output block of the tile: 6 MFMAs, the digit combine, then this lane's group of 8 signs.
+// One 16-output block of the tile in three parts: rd_mf_burst (fragments + 6 MFMAs), rd_mf_combine (the two digits
+// -> g) and rd_mf_tail (this lane's group of 8 signs, guard band, predecessor exchange).  RD_OPT_PIPE issues block
+// B+1's burst BEFORE block B's tail, so that a wave's own vector work runs under its own MFMAs instead of the wave
+// sitting out the ~200 cycles until the burst's results are back (the other waves of the SIMD are as often as not
+// waiting for memory).
 // xw + WOFF: LDS address this lane's (g6, g7) go to; xr: where its predecessors' are.
-template <int B, int DBG, int WOFF>
-__device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_u2v (&D)[9],
-                                            rd_h8 (&bf)[3], uint32_t dc_addr, uint32_t xw, uint32_t xr,
-                                            rd_mf_state &st, float *dg, int dleft) {
+template <int B, int DBG>
+__device__ __forceinline__ void rd_mf_burst(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_u2v (&D)[9],
+                                            rd_h8 (&bf)[3], uint32_t dc_addr, rd_f16v &ah, rd_f16v &al) {
     const rd_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // the hi accumulator starts at -D_hi in all sixteen positions (four broadcast reads, in flight under
     // the fragment preparation)
@@ -149,11 +156,6 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     if (B == 0) bf[0] = rd_mf_frag(D[0]); else bf[0] = bf[2];
     bf[1] = rd_mf_frag(D[2 * B + 1]);
     bf[2] = rd_mf_frag(D[2 * B + 2]);
-    // The six MFMAs go out as one burst with no vector instruction between them: a wave then sits in the
-    // matrix pipe's queue for ~192 cycles while the other waves of the SIMD issue their VALU work, instead
-    // of every wave stalling at an MFMA every few instructions (in-order issue: measured 1450 -> ... cycles/tile)
-    __builtin_amdgcn_sched_barrier(0);
-    rd_f16v ah, al;
     if (DBG == 4) {  // ablation: no matrix pipe, the vector work on stand-in values
         const rd_u4v q0 = __builtin_bit_cast(rd_u4v, bf[0]), q1 = __builtin_bit_cast(rd_u4v, bf[1]),
                      q2 = __builtin_bit_cast(rd_u4v, bf[2]);
@@ -169,17 +171,22 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
         al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], bf[0], zero, 0, 0, 0);
         ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], bf[1], ah, 0, 0, 0);
         al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], bf[1], al, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2], ah, 0, 0, 0);
-        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2], al, 0, 0, 0);
+        if (DBG != 9) {  // (9: a third fewer MFMAs, wrong results - what the matrix pipe costs in clock and time)
+            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2], ah, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2], al, 0, 0, 0);
+        }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG == 5) {  // ablation: the matrix pipe with next to no vector work behind it
-        st.W ^= __builtin_bit_cast(uint32_t, ah[0] + al[15]);
-        return;
-    }
-    float g[16];  // g[2r], g[2r+1] = re, im of output r of this lane's group
+}
+
+// g[2r], g[2r+1] = re, im of output r of this lane's group
+__device__ __forceinline__ void rd_mf_combine(const rd_f16v &ah, const rd_f16v &al, float (&g)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) g[i] = __builtin_fmaf(ah[i], 2048.0f, al[i]);
+}
+
+template <int B, int DBG, int WOFF>
+__device__ __forceinline__ void rd_mf_tail(const float (&g)[16], uint32_t xw, uint32_t xr, rd_mf_state &st, float *dg,
+                                           int dleft) {
     if (DBG == 3) {
 #pragma unroll
         for (int r = 0; r < 8; r++)  // the tile's last output (column 31, half 1, r = 7) belongs to the next tile
@@ -232,6 +239,27 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     }
 }
 
+// burst + combine + tail of one block, one after the other (the order without RD_OPT_PIPE).  The six MFMAs go out as
+// one burst with no vector instruction between them: a wave then sits in the matrix pipe's queue for ~192 cycles
+// while the other waves of the SIMD issue their VALU work, instead of every wave stalling at an MFMA every few
+// instructions (in-order issue).
+template <int B, int DBG, int WOFF>
+__device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_u2v (&D)[9],
+                                            rd_h8 (&bf)[3], uint32_t dc_addr, uint32_t xw, uint32_t xr,
+                                            rd_mf_state &st, float *dg, int dleft) {
+    rd_f16v ah, al;
+    __builtin_amdgcn_sched_barrier(0);
+    rd_mf_burst<B, DBG>(Ahi, Alo, D, bf, dc_addr, ah, al);
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG == 5) {  // ablation: the matrix pipe with next to no vector work behind it
+        st.W ^= __builtin_bit_cast(uint32_t, ah[0] + al[15]);
+        return;
+    }
+    float g[16];
+    rd_mf_combine(ah, al, g);
+    rd_mf_tail<B, DBG, WOFF>(g, xw, xr, st, dg, dleft);
+}
+
 // cache policy of the tile loads (the builtin's aux operand): 0 default, 2 = nt.  The input is streamed
 // once and never re-read: nt loads-only 0.330 ms (6.7 TB/s) against 0.358, loads + stores 0.427 against 0.462,
 // whole kernel 0.496 against 0.509, and the search kernel behind it finds more of the bits in cache.
@@ -239,7 +267,9 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
 #define RD_MF_LOAD_AUX 2
 #endif
 
-__device__ __forceinline__ void rd_mf_issue(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *img, int lane) {
+// halo_dma = false: the caller has put the 16 bytes before the tile into the image itself (RD_OPT_HALO)
+__device__ __forceinline__ void rd_mf_issue(const rd_layout &lay, uint32_t s, uint32_t ti, uint8_t *img, int lane,
+                                            bool halo_dma = true) {
     const uint8_t *src = lay.iq + (size_t)s * lay.stream_stride + (size_t)ti * RD_TILE_BYTES;
     const int perm = 8 * (lane & 7) + (lane >> 3);
     const __attribute__((address_space(1))) void *g0 = (const __attribute__((address_space(1))) void *)(src + perm * 16);
@@ -252,13 +282,21 @@ __device__ __forceinline__ void rd_mf_issue(const rd_layout &lay, uint32_t s, ui
     // the 16 bytes before the tile (previous tile, or the caller's history).  With zero history there
     // is nothing to read: the first run of the stream is re-evaluated exactly anyway.
     const bool has_halo = (ti > 0) || lay.hist_mode;
-    if (lane == 0)
+    if (lane == 0 && halo_dma)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (has_halo ? -16 : 0)),
                                          (__attribute__((address_space(3))) void *)(img), 16, 0, 0);
 }
 
+// the lane number from the exec-mask counters: inside the rarely taken paths below, so that no register holds a
+// lane-derived address for them across the whole tile loop (the allocator spilled those - and a reload is a scratch
+// load with a vmcnt(0) wait in the stretch between a tile's arrival and the next tile's loads)
+__device__ __forceinline__ int rd_lane_now() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
 __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count, uint32_t *fix_list, uint32_t fix_cap,
-                                            uint32_t *counters, int lane) {
+                                            uint32_t *counters) {
+    const int lane = rd_lane_now();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&counters[RD_CNT_FIX], count);
@@ -268,8 +306,8 @@ __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count
 }
 
 // Store the staged words: four tiles as one 16-byte store per lane, fewer tile by tile.
-__device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t nst, uint32_t *base, int lane,
-                                                   uint32_t stflags) {
+__device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t nst, uint32_t *base, uint32_t stflags) {
+    const int lane = rd_lane_now();
     if (nst == RD_MF_STAGE_TILES) {
 #pragma unroll
         for (int j = 0; j < RD_MF_STAGE_TILES / 4; j++) {
@@ -339,11 +377,36 @@ __device__ __forceinline__ void rd_mf_read_window(uint32_t a_prv, uint32_t a_own
                  : "memory");
 }
 
-// DBG: 0 product; 1 no global loads; 2 loads + LDS reads only; 3 also dumps g (dbg_g[tile][2048][2],
-// sample order); 4 = 1 without the MFMAs; 5 = 1 with the MFMAs and almost no vector work - 1, 2, 4, 5 are
-// timing ablations with garbage results.
-template <int DBG, int NBUF>
-__global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
+// In-kernel stamps (RD_OPT_STAMP, diagnostic library only; cdna_hip_programming.md section 7): one statement with
+// its own lgkmcnt(0), fenced against the scheduler on both sides.
+__device__ __forceinline__ uint64_t rd_stamp() {
+    uint64_t t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
+    uint64_t t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// DBG: 0 product; 3 also dumps g (dbg_g[tile][2048][2], sample order; the test hook).  Diagnostic library only
+// (-DRD_DIAG, librtldavis_hip_diag.so; garbage results): 1 no global loads; 2 loads + LDS reads + stores only;
+// 4 = 1 without the MFMAs; 5 = 1 with the MFMAs and almost no vector work; 6 loads only; 7 no guard band;
+// 9 = 16 of the 24 MFMAs per tile.
+// OPT (compile time): RD_OPT_PIPE block B+1's MFMAs before block B's vector work; RD_OPT_HALO the 16 bytes in front
+// of a tile come from the previous tile's registers inside a chunk (four LDS-DMA instructions per tile, not five);
+// RD_OPT_STAMP (diagnostic library) s_memtime stamps, per-wave sums in dbg_g.
+#define RD_OPT_PIPE 1
+#define RD_OPT_HALO 2
+#define RD_OPT_STAMP 4
+#define RD_STAMP_WORDS 12
+template <int DBG, int NBUF, int OPT>
+__global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
                                                          uint32_t chunk, uint32_t *fix_list, uint32_t fix_cap,
                                                          uint32_t *counters, float *dbg_g, uint32_t stflags) {
     // NBUF = 1 (default): one image buffer, tile i+1 in flight while tile i is computed, 4 workgroups per CU.
@@ -424,16 +487,34 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
     uint32_t nst = 0;             // tiles staged (wave-uniform)
     uint32_t *st_base = nullptr;  // word 0 of the first staged tile
     bool st_flush = false;        // the staged group ends here (next tile is not the next 64 words)
-    uint32_t rg_word = 0;         // a ragged last tile is stored word by word, predicated
-    uint32_t *rg_ptr = nullptr;
+    constexpr bool STAMP = (OPT & RD_OPT_STAMP) != 0;
+    // stamp sums (wave-uniform, scalar registers): cycles at the loop-top wait, from there to the last load issued,
+    // and in the arithmetic; the waits that follow an iteration with a word store apart
+    uint64_t sm_wait = 0, sm_gap = 0, sm_comp = 0, sm_wait_st = 0, sm_t0 = 0, sm_r0 = 0, sm_mark = 0, sm_wmax = 0;
+    uint32_t sm_iters = 0, sm_iters_st = 0;
+    bool sm_stored = false;
+    if (STAMP) { sm_t0 = rd_stamp(); sm_r0 = rd_stamp_real(); }
     if (LOADS && cur.tile < total_tiles) rd_mf_issue(lay, cur.s, cur.ti, img0, lane);
     if (NBUF == 2 && LOADS && nx1.tile < total_tiles) rd_mf_issue(lay, nx1.s, nx1.ti, img0 + RD_MF_IMG_PAD, lane);
+    if (STAMP) sm_mark = rd_stamp();
     while (cur.tile < total_tiles) {
         const uint32_t tile = cur.tile, s = cur.s, ti = cur.ti, inchunk = cur.inchunk;
+        uint64_t sm_a = 0;
+        if (STAMP) { sm_a = rd_stamp(); sm_comp += sm_a - sm_mark; }
         // this tile has landed when at most the next tile's five loads are outstanding (vmcnt counts in
         // issue order; the previous iteration's word store and list flush are older or harmless)
         if (NBUF == 2 && nx1.tile < total_tiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(grab) : : "memory");
+        uint64_t sm_b = 0;
+        if (STAMP) {
+            sm_b = rd_stamp();
+            const uint64_t w = sm_b - sm_a;
+            sm_wait += w;
+            if (w > sm_wmax) sm_wmax = w;
+            if (sm_stored) { sm_wait_st += w; sm_iters_st++; }
+            sm_iters++;
+            sm_stored = false;
+        }
         if (dynamic) {
             if (grab_pending) {  // asked for one iteration ago: the wait above covers it
                 nextc = rd_mf_chunk_at((uint64_t)nwaves + my_queue + (uint64_t)RD_NQUEUE * __builtin_amdgcn_readfirstlane(grab),
@@ -461,15 +542,28 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         // the window is in registers: this buffer takes the tile after next
         // stores of finished tiles go out here, before the loads (they share vmcnt, in issue order)
         if (nst == RD_MF_STAGE_TILES || (nst && st_flush)) {
-            rd_mf_store_staged(stage_addr, nst, st_base, lane, stflags);
+            rd_mf_store_staged(stage_addr, nst, st_base, stflags);
             nst = 0;
+            if (STAMP) sm_stored = true;
         }
-        if (rg_ptr) *rg_ptr = rg_word;
-        rg_ptr = nullptr;
         const rd_mf_pos nx2 = rd_mf_next(nx1, chunk, tiles_per_stream, nextc);
         const rd_mf_pos fetch = NBUF == 2 ? nx2 : nx1;
-        if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane);
+        // RD_OPT_HALO: when the tile fetched next is the one that follows this tile in its stream, the 16 bytes in
+        // front of it are this tile's last 16 - k-step 8 of column 31, in the registers of lanes 31 and 63 - and go
+        // into the image's halo slot by one ds_write_b64 instead of a fifth LDS-DMA instruction (a 16-byte request of
+        // its own through the whole memory pipe).  The window read above has completed (its lgkmcnt(0)), the next
+        // window read follows in LDS order; the four group loads do not touch the slot.
+        bool halo_dma = true;
+        if ((OPT & RD_OPT_HALO) && NBUF == 1) {
+            const bool follows = fetch.tile < total_tiles && fetch.s == s && fetch.ti == ti + 1;  // wave-uniform
+            if (follows) {
+                halo_dma = false;
+                if (n == 31) asm volatile("ds_write_b64 %0, %1" : : "v"(img_addr + 8 * h), "v"(D[8]) : "memory");
+            }
+        }
+        if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane, halo_dma);
         if (!(stflags & 4)) __builtin_amdgcn_s_setprio(0);
+        if (STAMP) { sm_mark = rd_stamp(); sm_gap += sm_mark - sm_b; }
 
         uint32_t word = 0, fbytes = 0;
         if (DBG == 2 || DBG == 6) {
@@ -481,10 +575,38 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
             stt.W = 0; stt.fbytes = 0; stt.g0r = 0.0f; stt.g0i = 0.0f;
             float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 8 * h + 1) * 2 : nullptr;
             const int dleft = RD_TILE_SAMPLES - (64 * n + 8 * h + 1);  // outputs of this lane inside the tile
-            rd_mf_block<0, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw, 0, stt, dg, dleft);
-            rd_mf_block<1, DBG, 1024>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr1, stt, dg, dleft);
-            rd_mf_block<2, DBG, 2048>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr2, stt, dg, dleft);
-            rd_mf_block<3, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw3, xr3, stt, dg, dleft);
+            if ((OPT & RD_OPT_PIPE) && DBG != 5) {
+                // block B+1's burst is issued before block B's tail: the tail's vector work has no use for the
+                // matrix pipe's results and runs under the MFMAs (the scheduler is free to interleave them; the
+                // fences only keep a burst behind the combine that frees its accumulator registers)
+                rd_f16v ah, al;
+                float g[16];
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_burst<0, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_combine(ah, al, g);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_burst<1, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
+                rd_mf_tail<0, DBG, 0>(g, xw, 0, stt, dg, dleft);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_combine(ah, al, g);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_burst<2, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
+                rd_mf_tail<1, DBG, 1024>(g, xw, xr1, stt, dg, dleft);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_combine(ah, al, g);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_burst<3, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
+                rd_mf_tail<2, DBG, 2048>(g, xw, xr2, stt, dg, dleft);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_mf_combine(ah, al, g);
+                rd_mf_tail<3, DBG, 0>(g, xw3, xr3, stt, dg, dleft);
+            } else {
+                rd_mf_block<0, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw, 0, stt, dg, dleft);
+                rd_mf_block<1, DBG, 1024>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr1, stt, dg, dleft);
+                rd_mf_block<2, DBG, 2048>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr2, stt, dg, dleft);
+                rd_mf_block<3, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw3, xr3, stt, dg, dleft);
+            }
             {   // block 0's first two numerators: W holds 30 bits, its bits 31, 30 are theirs
                 rd_f4v p = rd_lds_read16<0>(xr0);
                 rd_lds_wait(p);
@@ -548,17 +670,18 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
                 word &= (1u << left) - 1u;
                 gmask &= (1u << ((left + RD_GROUP - 1) / RD_GROUP)) - 1u;
             }
-            rg_word = word;
-            rg_ptr = &lay.bits[(size_t)s * lay.bits_stride + run];
+            // a ragged last tile of a stream is stored word by word, at once (it sits between the next tile's loads in
+            // vmcnt order: the next loop-top wait includes it - once per stream, and only for ragged streams)
+            lay.bits[(size_t)s * lay.bits_stride + run] = word;
         } else {
             gmask = 0;
         }
-        if (DBG == 1 || DBG == 2 || (DBG >= 4 && DBG != 7)) gmask = 0;  // (incl. 6)
+        if (DBG == 1 || DBG == 2 || (DBG >= 4 && DBG != 7)) gmask = 0;  // (incl. 6, 9)
         const uint64_t fm = (any_flag || !carry) ? __ballot(gmask != 0) : 0;
         if (fm) {
             const uint32_t nf = (uint32_t)__popcll(fm);
             if (npend + nf > RD_MF_PEND) {
-                rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, lane);
+                rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
                 npend = 0;
             }
             if (gmask)
@@ -571,9 +694,21 @@ __global__ __launch_bounds__(RD_MF_WG, 2) void k_demod_mfma(rd_layout lay, uint3
         nx1 = nx2;
         if (NBUF == 2) buf ^= 1;
     }
-    if (nst) rd_mf_store_staged(stage_addr, nst, st_base, lane, stflags);
-    if (rg_ptr) *rg_ptr = rg_word;
-    if (npend) rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, lane);
+    if (nst) rd_mf_store_staged(stage_addr, nst, st_base, stflags);
+    if (npend) rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
+    if (STAMP && dbg_g) {  // a buffer of its own: nothing else in the kernel reads it
+        const uint64_t t1 = rd_stamp(), r1 = rd_stamp_real();
+        sm_comp += t1 - sm_mark;
+        if (lane == 0) {
+            uint64_t *o = (uint64_t *)dbg_g + (size_t)wave_id * RD_STAMP_WORDS;
+            o[0] = sm_wait; o[1] = sm_gap; o[2] = sm_comp; o[3] = sm_wait_st;
+            o[4] = sm_iters; o[5] = sm_iters_st; o[6] = t1 - sm_t0; o[7] = r1 - sm_r0;
+            o[8] = sm_wmax; o[9] = sm_r0; o[10] = r1;
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[11] = xcc;
+        }
+    }
 }
 
 static int rd_mf_env(const char *name, int dflt) {
@@ -581,80 +716,150 @@ static int rd_mf_env(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g) {
-    const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
-    const uint64_t total64 = (uint64_t)lay.n_streams * tps;
-    if (total64 == 0) return;
-    const uint32_t total = (uint32_t)total64;
-    static uint32_t stflags = 0;
-    static int dbg = -1, chunk_env = 0, per_cu_env = 0, n_cu = 0, nbuf = 1, per_cu_occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (dbg < 0) {
-        dbg = rd_mf_env("RD_K1_DEBUG", 0);
-        chunk_env = rd_mf_env("RD_K1_CHUNK", 0);
+// What the shipped kernel is built with (-DRD_MF_PRODUCT_OPT=n overrides; the diagnostic library selects at run time)
+#ifndef RD_MF_PRODUCT_OPT
+#define RD_MF_PRODUCT_OPT RD_OPT_HALO
+#endif
+
+// Launch parameters read once per process.  A function-local static: initialised exactly once, also when several
+// threads make their first launch together (handles may be used from several threads, rd_api.hip).
+struct rd_mf_params {
+    int dbg = 0, opt = RD_MF_PRODUCT_OPT, nbuf = 1, chunk_env = 0, per_cu_env = 0, n_cu = 256;
+    uint32_t stflags = 0;
+    rd_mf_params() {
+        chunk_env = rd_mf_env("RD_K1_CHUNK", 0);          // tuning knobs: results do not depend on them
         per_cu_env = rd_mf_env("RD_K1_WGS_PER_CU", 0);
+#ifdef RD_DIAG
+        // timing ablations and A/B switches, wrong results for most of them: the diagnostic library only
+        dbg = rd_mf_env("RD_K1_DEBUG", 0);
+        opt = rd_mf_env("RD_K1_OPT", RD_MF_PRODUCT_OPT);
         nbuf = rd_mf_env("RD_K1_NBUF", 1) == 2 ? 2 : 1;
         stflags = (uint32_t)rd_mf_env("RD_K1_STFLAGS", 0);
+#endif
         int dev = 0;
-        hipGetDevice(&dev);
         hipDeviceProp_t prop;
-        n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                   ? prop.multiProcessorCount : 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
     }
-    const int variant = dbg_g ? 3 : (dbg == 1 || dbg == 2 || (dbg >= 4 && dbg <= 7)) ? dbg : 0;
+};
+static const rd_mf_params &rd_mf_get_params() {
+    static const rd_mf_params p;
+    return p;
+}
+
+#ifdef RD_DIAG
+// stamps of the last RD_OPT_STAMP launch: RD_STAMP_WORDS uint64 per wave (diagnostic library only)
+static uint64_t *g_stamp_buf = nullptr;
+static uint32_t g_stamp_waves = 0;
+extern "C" int rd_diag_read_stamps(uint64_t *out, uint32_t cap_waves, uint32_t *n_waves) {
+    if (!g_stamp_buf || !n_waves) return RD_ERR_STATE;
+    if (hipDeviceSynchronize() != hipSuccess) return RD_ERR_DEVICE;
+    *n_waves = g_stamp_waves;
+    const uint32_t n = g_stamp_waves < cap_waves ? g_stamp_waves : cap_waves;
+    if (n && hipMemcpy(out, g_stamp_buf, (size_t)n * RD_STAMP_WORDS * 8, hipMemcpyDeviceToHost) != hipSuccess) return RD_ERR_DEVICE;
+    return RD_OK;
+}
+extern "C" int rd_diag_variant(int *dbg, int *opt, int *nbuf, uint32_t *stflags) {
+    const rd_mf_params &P = rd_mf_get_params();
+    if (dbg) *dbg = P.dbg;
+    if (opt) *opt = P.opt;
+    if (nbuf) *nbuf = P.nbuf;
+    if (stflags) *stflags = P.stflags;
+    return RD_OK;
+}
+#endif
+
+struct rd_mf_launch_args {
+    rd_layout lay;
+    uint32_t tps, total;
+    uint64_t total64;
+    uint32_t *fix_list, fix_cap, *counters;
+    hipStream_t st;
+    hipEvent_t ev_start, ev_stop;
+    float *dbg_g;
+};
+
+template <int D, int NB, int OPT>
+static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
+    const rd_mf_params &P = rd_mf_get_params();
     // persistent grid sized from the occupancy API (registers and LDS of the variant actually launched)
-    if (!per_cu_occ[variant]) {  // (nbuf is fixed per process)
+    static const int per_cu_occ = [] {
         int occ = 0;
-        hipError_t e = hipErrorUnknown;
-        switch (variant) {
-            case 0: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<0, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<0, 2>, RD_MF_WG, 0)); break;
-            case 1: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<1, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<1, 2>, RD_MF_WG, 0)); break;
-            case 2: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<2, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<2, 2>, RD_MF_WG, 0)); break;
-            case 4: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<4, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<4, 2>, RD_MF_WG, 0)); break;
-            case 5: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<5, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<5, 2>, RD_MF_WG, 0)); break;
-            case 6: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<6, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<6, 2>, RD_MF_WG, 0)); break;
-            case 7: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<7, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<7, 2>, RD_MF_WG, 0)); break;
-            default: e = (nbuf == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<3, 1>, RD_MF_WG, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<3, 2>, RD_MF_WG, 0)); break;
-        }
-        per_cu_occ[variant] = (e == hipSuccess && occ >= 1) ? (occ > 8 ? 8 : occ) : 2;
-    }
-    // (three workgroups per CU instead of the four that fit: within the run-to-run noise, +-2 %)
-    const int per_cu = (per_cu_env >= 1 && per_cu_env <= 8) ? per_cu_env : per_cu_occ[variant];
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<D, NB, OPT>, RD_MF_WG, 0);
+        return (e == hipSuccess && occ >= 1) ? (occ > 8 ? 8 : occ) : 2;
+    }();
+    // (three workgroups per CU instead of the four that fit: 4 % slower)
+    const int per_cu = (P.per_cu_env >= 1 && P.per_cu_env <= 8) ? P.per_cu_env : per_cu_occ;
     // Tiles per chunk: a multiple of the 4-tile store groups.  With the work queues (default) 16: the chunks past a
     // wave's first are handed out on demand, the waves that run faster take more of them, and shorter chunks
     // even the finish out (0.459 ms; 28: 0.471, 12: 0.466, 8: 0.465 but a longer fix-up list).  With equal shares
     // (RD_K1_STFLAGS & 4096) 28, the best of a sweep from 8 to 66 on 4096 x 132 tiles (profiles/r02_chunk_sweep.txt).
     // A small workload gets shorter chunks, down to one store group, until every resident wave has one.
-    uint32_t chunk = chunk_env > 0 ? (uint32_t)chunk_env : ((stflags & 4096) ? 28 : 16);
-    if (chunk_env <= 0) {
-        const uint64_t waves = (uint64_t)n_cu * per_cu * RD_MF_WAVES;
-        while (chunk > RD_MF_STAGE_TILES && total64 / chunk < waves) chunk -= RD_MF_STAGE_TILES;
+    uint32_t chunk = P.chunk_env > 0 ? (uint32_t)P.chunk_env : ((P.stflags & 4096) ? 28 : 16);
+    if (P.chunk_env <= 0) {
+        const uint64_t waves = (uint64_t)P.n_cu * per_cu * RD_MF_WAVES;
+        while (chunk > RD_MF_STAGE_TILES && a.total64 / chunk < waves) chunk -= RD_MF_STAGE_TILES;
     }
-    if (chunk > total) chunk = total;
-    const uint64_t chunks = (total64 + chunk - 1) / chunk;
+    if (chunk > a.total) chunk = a.total;
+    const uint64_t chunks = (a.total64 + chunk - 1) / chunk;
     uint64_t wgs = (chunks + RD_MF_WAVES - 1) / RD_MF_WAVES;
-    const uint64_t max_wgs = (uint64_t)n_cu * per_cu;
+    const uint64_t max_wgs = (uint64_t)P.n_cu * per_cu;
     if (wgs > max_wgs) wgs = max_wgs;
-#define RD_LAUNCH_MF2(D, NB)                                                                                         \
-    do {                                                                                                             \
-        if (ev_start || ev_stop)                                                                                     \
-            hipExtLaunchKernelGGL((k_demod_mfma<D, NB>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, st, ev_start,       \
-                                  ev_stop, 0, lay, tps, total, chunk, fix_list, fix_cap, counters, dbg_g, stflags);  \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_demod_mfma<D, NB>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, st, lay, tps, total,   \
-                               chunk, fix_list, fix_cap, counters, dbg_g, stflags);                                  \
-    } while (0)
-#define RD_LAUNCH_MF(D) do { if (nbuf == 1) RD_LAUNCH_MF2(D, 1); else RD_LAUNCH_MF2(D, 2); } while (0)
-    if (variant == 3) RD_LAUNCH_MF(3);
-    else if (variant == 1) RD_LAUNCH_MF(1);
-    else if (variant == 2) RD_LAUNCH_MF(2);
-    else if (variant == 4) RD_LAUNCH_MF(4);
-    else if (variant == 5) RD_LAUNCH_MF(5);
-    else if (variant == 6) RD_LAUNCH_MF(6);
-    else if (variant == 7) RD_LAUNCH_MF(7);
-    else RD_LAUNCH_MF(0);
-#undef RD_LAUNCH_MF
-#undef RD_LAUNCH_MF2
+    float *dbg = a.dbg_g;
+#ifdef RD_DIAG
+    if (OPT & RD_OPT_STAMP) {
+        const uint32_t nw = (uint32_t)wgs * RD_MF_WAVES;
+        if (nw > g_stamp_waves || !g_stamp_buf) {
+            if (g_stamp_buf) hipFree(g_stamp_buf);
+            g_stamp_buf = nullptr;
+            if (hipMalloc(&g_stamp_buf, (size_t)nw * RD_STAMP_WORDS * 8) != hipSuccess) g_stamp_buf = nullptr;
+        }
+        g_stamp_waves = g_stamp_buf ? nw : 0;
+        dbg = (float *)g_stamp_buf;
+    }
+#endif
+    if (a.ev_start || a.ev_stop)
+        hipExtLaunchKernelGGL((k_demod_mfma<D, NB, OPT>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.ev_start,
+                              a.ev_stop, 0, a.lay, a.tps, a.total, chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags);
+    else
+        hipLaunchKernelGGL((k_demod_mfma<D, NB, OPT>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.lay, a.tps, a.total,
+                           chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags);
+}
+
+void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g) {
+    rd_mf_launch_args a;
+    a.lay = lay;
+    a.tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
+    a.total64 = (uint64_t)lay.n_streams * a.tps;
+    if (a.total64 == 0) return;
+    a.total = (uint32_t)a.total64;
+    a.fix_list = fix_list; a.fix_cap = fix_cap; a.counters = counters;
+    a.st = st; a.ev_start = ev_start; a.ev_stop = ev_stop; a.dbg_g = dbg_g;
+    if (dbg_g) {  // the test hook: raw filter outputs as well
+        rd_mf_launch_variant<3, 1, RD_MF_PRODUCT_OPT>(a);
+        return;
+    }
+#ifdef RD_DIAG
+    const rd_mf_params &P = rd_mf_get_params();
+    const int key = P.dbg * 100 + P.nbuf * 10 + P.opt;
+    switch (key) {
+#define RD_V(D, NB, O) case (D) * 100 + (NB) * 10 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
+        RD_V(0, 1, 0) RD_V(0, 1, 1) RD_V(0, 1, 2) RD_V(0, 1, 3) RD_V(0, 1, 4) RD_V(0, 1, 5) RD_V(0, 1, 6) RD_V(0, 1, 7)
+        RD_V(1, 1, 0) RD_V(1, 1, 1)
+        RD_V(2, 1, 0) RD_V(2, 1, 2) RD_V(2, 1, 4) RD_V(2, 1, 6)
+        RD_V(6, 1, 0) RD_V(6, 1, 2) RD_V(6, 1, 4) RD_V(6, 1, 6)
+        RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
+        RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
+        RD_V(0, 2, 0)
+#undef RD_V
+        default:
+            fprintf(stderr, "[rd diag] no kernel variant RD_K1_DEBUG=%d RD_K1_NBUF=%d RD_K1_OPT=%d is compiled in\n", P.dbg, P.nbuf, P.opt);
+            abort();
+    }
+#else
+    rd_mf_launch_variant<0, 1, RD_MF_PRODUCT_OPT>(a);
+#endif
 }
 
 // Test hook (tests/test_gpu_mfma.py): run the kernel on host data, return the raw filter outputs g

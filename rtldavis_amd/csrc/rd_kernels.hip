@@ -201,15 +201,37 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
     if (npend) rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
 }
 
+// Environment switches of this file, read once per process (function-local static: thread-safe first use).
+struct rd_k_params {
+    int impl_mfma = 1, per_cu_valu = 7, dbg = 0, npk = RD_NPK_DEFAULT, slice_two = 1, search_cap = 32 / 4;
+    rd_k_params() {
+        const char *e = getenv("RD_K1_IMPL");  // "valu": the round-1 demod kernel (FIR on the VALU) for A/B runs
+        impl_mfma = (e && e[0] == 'v') ? 0 : 1;
+        e = getenv("RD_K1_WGS_PER_CU");
+        per_cu_valu = e ? atoi(e) : 7;
+        if (per_cu_valu < 1 || per_cu_valu > 8) per_cu_valu = 7;
+        e = getenv("RD_SLICE_IMPL");  // "wave": the one-kernel slice on the batch path as well (A/B)
+        slice_two = (e && e[0] == 'w') ? 0 : 1;
+        e = getenv("RD_K2_WGS_PER_CU");  // tuning knob of k_search
+        search_cap = e ? atoi(e) : 32 / 4;
+        if (search_cap < 1 || search_cap > 64) search_cap = 32 / 4;
+#ifdef RD_DIAG
+        e = getenv("RD_K1_DEBUG");  // timing ablations with garbage results: the diagnostic library only
+        dbg = e ? atoi(e) : 0;
+        e = getenv("RD_K1_NPK");    // packed FIR steps per output, for tuning sweeps
+        if (e) npk = atoi(e);
+#endif
+    }
+};
+static const rd_k_params &rd_k_get_params() {
+    static const rd_k_params p;
+    return p;
+}
+
 void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                      hipEvent_t ev_start, hipEvent_t ev_stop) {
-    // RD_K1_IMPL=valu keeps the round-1 kernel (FIR on the VALU) for A/B runs; default: matrix pipe
-    static int impl = -1;
-    if (impl < 0) {
-        const char *e = getenv("RD_K1_IMPL");
-        impl = (e && e[0] == 'v') ? 0 : 1;
-    }
-    if (impl == 1) {
+    const rd_k_params &P = rd_k_get_params();
+    if (P.impl_mfma) {
         rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop);
         return;
     }
@@ -218,22 +240,9 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
     const uint64_t total = (uint64_t)lay.n_streams * tps;
     uint64_t wgs = (total + RD_WAVES - 1) / RD_WAVES;
     // persistent grid: workgroups per CU (72 VGPRs and 18.5 KiB LDS admit 7); RD_K1_WGS_PER_CU overrides
-    static int per_cu = 0;
-    if (!per_cu) {
-        const char *e = getenv("RD_K1_WGS_PER_CU");
-        per_cu = e ? atoi(e) : 7;
-        if (per_cu < 1 || per_cu > 8) per_cu = 7;
-    }
-    const uint64_t max_wgs = 256ull * per_cu;
+    const uint64_t max_wgs = 256ull * P.per_cu_valu;
     if (wgs > max_wgs) wgs = max_wgs;
     if (wgs == 0) return;
-    static int dbg = -1, npk = RD_NPK_DEFAULT;
-    if (dbg < 0) {
-        const char *e = getenv("RD_K1_DEBUG");  // timing ablations (see k_demod_bits)
-        dbg = e ? atoi(e) : 0;
-        const char *n = getenv("RD_K1_NPK");  // packed FIR steps per output, for tuning sweeps
-        if (n) npk = atoi(n);
-    }
     // With events given, the dispatch itself carries them (hipExtLaunchKernelGGL): its begin / end
     // timestamps, without the marker packets of hipEventRecord that idle the GPU for ~6 us each.
 #define RD_LAUNCH_K1(D, N)                                                                                          \
@@ -245,15 +254,17 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
             hipLaunchKernelGGL((k_demod_bits<D, N>), dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps,        \
                                fix_list, fix_cap, counters);                                                        \
     } while (0)
-    if (dbg == 1) RD_LAUNCH_K1(1, RD_NPK_DEFAULT);
-    else if (dbg == 2) RD_LAUNCH_K1(2, RD_NPK_DEFAULT);
-    else if (npk == 0) RD_LAUNCH_K1(0, 0);
-    else if (npk == 2) RD_LAUNCH_K1(0, 2);
-    else if (npk == 4) RD_LAUNCH_K1(0, 4);
-    else if (npk == 6) RD_LAUNCH_K1(0, 6);
-    else if (npk == 7) RD_LAUNCH_K1(0, 7);
-    else if (npk == 9) RD_LAUNCH_K1(0, 9);
-    else RD_LAUNCH_K1(0, RD_NPK_DEFAULT);
+#ifdef RD_DIAG
+    if (P.dbg == 1) { RD_LAUNCH_K1(1, RD_NPK_DEFAULT); return; }
+    if (P.dbg == 2) { RD_LAUNCH_K1(2, RD_NPK_DEFAULT); return; }
+    if (P.npk == 0) { RD_LAUNCH_K1(0, 0); return; }
+    if (P.npk == 2) { RD_LAUNCH_K1(0, 2); return; }
+    if (P.npk == 4) { RD_LAUNCH_K1(0, 4); return; }
+    if (P.npk == 6) { RD_LAUNCH_K1(0, 6); return; }
+    if (P.npk == 7) { RD_LAUNCH_K1(0, 7); return; }
+    if (P.npk == 9) { RD_LAUNCH_K1(0, 9); return; }
+#endif
+    RD_LAUNCH_K1(0, RD_NPK_DEFAULT);
 #undef RD_LAUNCH_K1
 }
 
@@ -560,12 +571,7 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
     const long groups = (p_hi - base) / (32 * RD_SEARCH_OUT) + 1;
     const uint64_t total = (uint64_t)n_streams * groups;
     uint64_t wgs = (total + 64 * RD_SEARCH_WAVES - 1) / (64 * RD_SEARCH_WAVES);
-    static int cap = 0;
-    if (!cap) {
-        const char *e = getenv("RD_K2_WGS_PER_CU");  // tuning knob
-        cap = e ? atoi(e) : 32 / RD_SEARCH_WAVES;  // 8 waves per SIMD
-        if (cap < 1 || cap > 64) cap = 32 / RD_SEARCH_WAVES;
-    }
+    const int cap = rd_k_get_params().search_cap;  // 8 waves per SIMD unless RD_K2_WGS_PER_CU says otherwise
     if (wgs > 256ull * cap) wgs = 256ull * cap;
     // the Davis configuration (protocol.py:68-76): 14 samples/symbol, preamble 1100101110001001
     // (bit m of the mask = symbol m -> 0x91D3)
@@ -1146,8 +1152,7 @@ int rd_launch_slice(const rd_layout &lay, const uint32_t *bits, size_t bits_stri
                     void *tasks) {
     rd_u8_src src;
     src.lay = lay;
-    static int two = -1;
-    if (two < 0) { const char *e = getenv("RD_SLICE_IMPL"); two = (e && e[0] == 'w') ? 0 : 1; }  // "wave": the one-kernel form (A/B)
+    const int two = rd_k_get_params().slice_two;  // RD_SLICE_IMPL=wave: the one-kernel form (A/B)
     // the Davis shape in the batch path: lane-per-match classification, then one wave per surviving packet
     if (two && tasks && batch_mode && recs && !recs_host && cfg.S == 14 && cfg.K == 80 && n_bits < (1l << 30)) {
         const uint32_t cg = std::min<uint32_t>((match_cap + 255) / 256, 1024);

@@ -282,7 +282,12 @@ class MultiDemodulator:
         for i in range(n.value):
             r = self._recs[i]
             data = np.frombuffer(bytes(r.data[: r.nbytes]), dtype=np.uint8)
-            out[r.stream].append(Packet(int(r.index), data, float(r.rssi), float(r.snr)))
+            snr = float(r.snr)
+            if snr == -math.inf:
+                # as Demodulator._packets_from: the reference's math.log10(0) raises out of that stream's
+                # demodulate() (dsp.py:231-236).  One exception for the whole round: the streams run in lock step.
+                raise ValueError("math domain error")
+            out[r.stream].append(Packet(int(r.index), data, float(r.rssi), snr))
         return out
 
     def demodulate(self, blocks: np.ndarray) -> List[List[Packet]]:

@@ -1,25 +1,33 @@
 """DSP worker loops on the GPU demodulator.
 
-Counterpart of the reference's ``worker.worker_main`` (src/rtldavis/worker.py:10-58): blocks arrive on
-a ``multiprocessing.Queue`` (``None`` stops the loop, a 1 s poll keeps it interruptible), each block
-is demodulated and parsed, messages go to ``result_queue``; an exception in the DSP step is logged
-and the block dropped (worker.py:56-58).  Two things differ, both invisible to the caller:
+``worker_main(data_queue, result_queue, station_id, symbol_length, log_level)`` has the reference's signature
+(src/rtldavis/worker.py:10-16) and is a drop-in ``multiprocessing.Process`` target for runners/rtlsdr.py:61-65: it
+builds the reference's own ``protocol.Parser`` on ``rtldavis_amd.dsp`` (module swap) and
+runs ``worker_loop``.
 
-* the demodulator call is split into ``submit`` / ``fetch`` (rd_demod_submit / rd_demod_fetch), so
-  the host-to-device copy of block i+1 runs beside the kernels of block i and the loop parses block
-  i while block i+1 is on the GPU - the pickled-queue hop of runners/rtlsdr.py:100-103 stays the
-  caller's, the wait inside ``demodulate`` is gone;
+``worker_loop`` is the reference's loop (worker.py:34-58): blocks arrive on a ``multiprocessing.Queue`` (``None`` stops
+the loop, a 1 s poll keeps it interruptible), each block is demodulated and parsed, messages go to ``result_queue``;
+an exception in the DSP step is logged and the block dropped (worker.py:56-58).  Two things differ, both invisible to
+the caller:
+
+* the demodulator call is split into ``submit`` / ``fetch`` (rd_demod_submit / rd_demod_fetch): a block is handed to
+  the GPU as soon as it arrives and the loop goes back to the queue - waiting for, and unpickling, block i+1
+  (runners/rtlsdr.py:100-103 puts one pickled ndarray per block) runs beside block i's copy and kernels.  Block i is
+  fetched AND parsed before block i+1 is submitted: ``Parser.parse`` reads ``demodulator.discriminated`` of the block
+  it was given (protocol.py:304-311), which needs a handle with nothing in flight - so there is never more than one
+  block on the GPU here, and ``parse()`` itself does not overlap GPU work;
 * ``multi_worker_main`` drains several ``data_queue``s (one per dongle / hop channel) into ONE
   ``MultiDemodulator`` launch per round.
 
-The protocol layer is not rebuilt here: ``parser_factory`` supplies the reference's own
-``protocol.Parser`` (with ``rtldavis.dsp`` swapped for ``rtldavis_amd.dsp``) or any
-object with ``.cfg``, ``.demodulator`` and ``.parse(packets)``.
+The protocol layer is not rebuilt here: the parser is the reference's ``protocol.Parser`` (or, for ``worker_loop``,
+any object with ``.cfg``, ``.demodulator`` and ``.parse(packets)`` that ``parser_factory`` supplies).
 """
 from __future__ import annotations
 
+import importlib
 import logging
 import queue
+import sys
 from typing import Callable, List, Optional, Sequence
 
 import numpy as np
@@ -39,9 +47,37 @@ def _get(q, timeout: float):
     return samples, False
 
 
-def worker_main(data_queue, result_queue, parser_factory: Callable[[], object],
+# The reference package whose ``protocol.Parser`` worker_main builds (a test points this at a stand-in).
+REFERENCE_PACKAGE = "rtldavis"
+
+
+def reference_parser_factory(station_id: Optional[int], symbol_length: int) -> Callable[[], object]:
+    """``lambda: protocol.Parser(symbol_length=..., station_id=...)`` (worker.py:29) with ``<package>.dsp`` swapped
+    for ``rtldavis_amd.dsp`` first - what INTEGRATION.md section 2 adds to the reference's ``__init__``; done here
+    as well so that the entry point works on an unmodified checkout.  The swap must precede the first import of
+    ``<package>.protocol`` in this process (its ``from . import dsp`` binds the module once)."""
+    def make():
+        pkg = REFERENCE_PACKAGE
+        importlib.import_module(pkg)
+        sys.modules[pkg + ".dsp"] = dsp
+        protocol = importlib.import_module(pkg + ".protocol")
+        if getattr(protocol, "dsp", dsp) is not dsp:
+            raise RuntimeError(f"{pkg}.protocol was imported before the dsp swap: import rtldavis_amd.worker first, "
+                               "or set RTLDAVIS_BACKEND=hip as INTEGRATION.md section 2 describes")
+        return protocol.Parser(symbol_length=symbol_length, station_id=station_id)
+    return make
+
+
+def worker_main(data_queue, result_queue, station_id: Optional[int], symbol_length: int, log_level: int) -> None:
+    """Drop-in for the reference's ``worker.worker_main`` (worker.py:10-16, same positional arguments): the target of
+    ``multiprocessing.Process(target=worker_main, args=(data_queue, result_queue, args.station_id, 14, log_level))``
+    at runners/rtlsdr.py:61-65 needs no edit beyond the import."""
+    worker_loop(data_queue, result_queue, reference_parser_factory(station_id, symbol_length), log_level)
+
+
+def worker_loop(data_queue, result_queue, parser_factory: Callable[[], object],
                 log_level: int = logging.INFO, poll_s: float = 1.0) -> None:
-    """worker.worker_main (worker.py:10-58) with the demodulator pipelined one block deep.
+    """The loop of worker.worker_main (worker.py:18-58) on the submit / fetch halves of the demodulator.
 
     ``parser_factory()`` must return the parser (reference: ``protocol.Parser(symbol_length=...,
     station_id=...)``, worker.py:29); its ``demodulator`` has to be an ``rtldavis_amd.dsp.Demodulator``.
@@ -67,6 +103,16 @@ def worker_main(data_queue, result_queue, parser_factory: Callable[[], object],
                 result_queue.put(msg)
         except Exception as e:  # worker.py:56-58: log, drop the block, go on
             logger.error(f"Error in DSP loop: {e}")
+            # a fetch that failed on the device side leaves its block in flight: take it out, or every later
+            # fetch would hand back the block before the one asked for
+            try:
+                while getattr(dem, "inflight", 0):
+                    dem.fetch()
+            except Exception:
+                try:
+                    dem.reset()
+                except Exception as e2:
+                    logger.error(f"Error in DSP loop: demodulator reset failed: {e2}")
         pending = False
 
     while True:
@@ -131,6 +177,7 @@ def multi_worker_main(data_queues: Sequence, result_queue, parser_factory: Calla
         stop = False
         for q in data_queues:
             while True:
+                samples = None
                 try:
                     samples, stop = _get(q, poll_s)
                 except KeyboardInterrupt:

@@ -310,7 +310,7 @@ def test_full_size_4096_streams_properties(dsp, batchmod, golden_streams):
     cnt = bd.counters()
     assert cnt["matches"] % 64 == 0  # 64 identical copies of each unique stream
     # (the fix-up list is not a multiple of 64: the forced entries at chunk starts follow the global tile index,
-    # 28 tiles per chunk against 132 per stream)
+    # 16 tiles per chunk - the work-queue default, rd_demod_mfma.hip - against 132 per stream)
     assert 0 < cnt["fixup_runs"] < 0.05 * 4096 * 8448
 
 
@@ -554,7 +554,7 @@ def test_worker_loops_on_the_gpu(dsp, golden_streams):
         dq.put(raw[2 * B * b: 2 * B * (b + 1)])
     dq.put(np.zeros(7, np.uint8))  # a bad block is logged and dropped (worker.py:56-58), the loop goes on
     dq.put(None)
-    t = threading.Thread(target=worker.worker_main, args=(dq, rq, Parser), kwargs=dict(poll_s=0.05))
+    t = threading.Thread(target=worker.worker_loop, args=(dq, rq, Parser), kwargs=dict(poll_s=0.05))
     t.start(); t.join(60)
     assert not t.is_alive()
     got = []

@@ -35,7 +35,7 @@ class FakeParser:
         return [("msg", p) for p in packets]
 
 
-def test_worker_main_order_stop_and_errors():
+def test_worker_loop_order_stop_and_errors():
     from rtldavis_amd import worker
     dq, rq = queue.Queue(), queue.Queue()
     for i in range(6):
@@ -49,7 +49,7 @@ def test_worker_main_order_stop_and_errors():
         parsers.append(FakeParser())
         return parsers[-1]
 
-    t = threading.Thread(target=worker.worker_main, args=(dq, rq, factory), kwargs=dict(poll_s=0.02))
+    t = threading.Thread(target=worker.worker_loop, args=(dq, rq, factory), kwargs=dict(poll_s=0.02))
     t.start(); t.join(20)
     assert not t.is_alive()
     got = []
@@ -62,15 +62,15 @@ def test_worker_main_order_stop_and_errors():
     assert parsers[0].demodulator.flight == []
 
 
-def test_worker_main_survives_a_failing_factory_and_idle_polls():
+def test_worker_loop_survives_a_failing_factory_and_idle_polls():
     from rtldavis_amd import worker
 
     def bad():
         raise RuntimeError("no parser")
 
-    worker.worker_main(queue.Queue(), queue.Queue(), bad, poll_s=0.01)  # returns, like worker.py:30-32
+    worker.worker_loop(queue.Queue(), queue.Queue(), bad, poll_s=0.01)  # returns, like worker.py:30-32
     dq, rq = queue.Queue(), queue.Queue()
-    t = threading.Thread(target=worker.worker_main, args=(dq, rq, FakeParser), kwargs=dict(poll_s=0.01))
+    t = threading.Thread(target=worker.worker_loop, args=(dq, rq, FakeParser), kwargs=dict(poll_s=0.01))
     t.start()
     import time
     time.sleep(0.1)           # idle polling
@@ -80,3 +80,111 @@ def test_worker_main_survives_a_failing_factory_and_idle_polls():
     dq.put(None)
     t.join(10)
     assert not t.is_alive()
+
+
+class FlakyDem(FakeDem):
+    """fetch() fails on the device side once: the block stays in flight (rd_demod_fetch returned an error)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fail_next = True
+
+    @property
+    def inflight(self):
+        return len(self.flight)
+
+    def fetch(self):
+        if self.fail_next and self.flight and self.flight[0] == 1:
+            self.fail_next = False
+            raise RuntimeError("device lost")
+        return super().fetch()
+
+
+def test_worker_loop_drains_the_handle_after_a_failed_fetch():
+    from rtldavis_amd import worker
+
+    class P(FakeParser):
+        def __init__(self):
+            super().__init__()
+            self.demodulator = FlakyDem()
+
+    dq, rq = queue.Queue(), queue.Queue()
+    for i in (0, 1, 2, 4):
+        dq.put(np.full(4, i, np.uint8))
+    dq.put(None)
+    t = threading.Thread(target=worker.worker_loop, args=(dq, rq, P), kwargs=dict(poll_s=0.02))
+    t.start(); t.join(20)
+    assert not t.is_alive()
+    got = []
+    while not rq.empty():
+        got.append(rq.get())
+    # block 1 is lost with its failed fetch; blocks 2 and 4 come back as themselves, not shifted by one
+    assert got == [("msg", 0), ("msg", 2), ("msg", 4)]
+
+
+def test_worker_main_has_the_reference_signature_and_builds_the_reference_parser(tmp_path, monkeypatch):
+    """worker.worker_main(data_queue, result_queue, station_id, symbol_length, log_level) - the reference's own
+    positional arguments (src/rtldavis/worker.py:10-16, called at runners/rtlsdr.py:61-65) - on a stand-in package
+    whose protocol module does `from . import dsp` like the reference's (protocol.py:1-20)."""
+    import inspect
+    import logging
+    import sys
+    from rtldavis_amd import dsp as hip_dsp, worker
+
+    assert list(inspect.signature(worker.worker_main).parameters) == [
+        "data_queue", "result_queue", "station_id", "symbol_length", "log_level"]
+    pkg = tmp_path / "fakeref"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "dsp.py").write_text("raise ImportError('the CPU dsp must not be imported once the swap is in place')\n")
+    (pkg / "protocol.py").write_text(
+        "from . import dsp\n"
+        "class _Dem:\n"
+        "    def __init__(self): self.flight = []\n"
+        "    def submit(self, b): self.flight.append(int(b[0]))\n"
+        "    def fetch(self): return [self.flight.pop(0)]\n"
+        "class Parser:\n"
+        "    def __init__(self, symbol_length, station_id=None):\n"
+        "        self.args = (symbol_length, station_id)\n"
+        "        self.dsp_module = dsp\n"
+        "        self.cfg = dsp.PacketConfig(19200, symbol_length, 16, 80, '1100101110001001', 8192)\n"
+        "        self.demodulator = _Dem()\n"
+        "    def parse(self, packets):\n"
+        "        return [(self.args, self.dsp_module.__name__, p) for p in packets]\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    monkeypatch.setattr(worker, "REFERENCE_PACKAGE", "fakeref")
+    for k in [k for k in sys.modules if k == "fakeref" or k.startswith("fakeref.")]:
+        del sys.modules[k]
+    dq, rq = queue.Queue(), queue.Queue()
+    dq.put(np.full(4, 5, np.uint8))
+    dq.put(None)
+    t = threading.Thread(target=worker.worker_main, args=(dq, rq, 3, 14, logging.WARNING))
+    t.start(); t.join(20)
+    assert not t.is_alive()
+    assert rq.get(timeout=2) == ((14, 3), hip_dsp.__name__, 5)
+    assert sys.modules["fakeref.dsp"] is hip_dsp
+    for k in [k for k in sys.modules if k == "fakeref" or k.startswith("fakeref.")]:
+        del sys.modules[k]
+
+
+def test_multi_worker_interrupt_on_the_first_get_stops_cleanly(monkeypatch):
+    """a KeyboardInterrupt raised by the very first queue read used to leave `samples` unbound."""
+    from rtldavis_amd import worker
+
+    class Q:
+        def get(self, timeout=None):
+            raise KeyboardInterrupt
+
+    class M:
+        def __init__(self, cfg, n):
+            self.cfg = cfg
+
+    class Cfg:
+        block_size = 2
+
+    class P:
+        cfg = Cfg()
+        demodulator = None
+
+    monkeypatch.setattr(worker.dsp, "MultiDemodulator", M)
+    worker.multi_worker_main([Q()], queue.Queue(), lambda k: P(), poll_s=0.01)  # returns instead of raising

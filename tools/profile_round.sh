@@ -49,6 +49,6 @@ timeout -k 10 200 python3 $ROOT/tools/stream_latency.py > $OUT/stream_latency.tx
 cat $OUT/stream_latency.txt | tee -a $OUT/progress.log
 
 step "8/8 N = 2 rehearsal on one GPU (code path only, not a measurement)"
-timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $ROOT/bench.py --gpus 2 --steps 6 --warmup 2 --rehearse-shared-gpu --streams 1024 > $OUT/rehearse_shared_gpu.txt 2>&1
+timeout -k 10 400 python3 $ROOT/bench.py --gpus 2 --steps 6 --warmup 2 --rehearse-shared-gpu --streams 1024 --sustain 0 > $OUT/rehearse_shared_gpu.txt 2>&1
 tail -c 600 $OUT/rehearse_shared_gpu.txt | tee -a $OUT/progress.log
 step "done"
