@@ -281,6 +281,14 @@ struct rd_batch {
     uint32_t spec_recs = 1024;       // records copied back speculatively with the counters
     uint64_t last_fix = 0, last_match = 0;
     rd_timing last_timing = {};
+    // The ordered tail (rd_launch_tail_ordered): records arrive in the reference's order with the per-call duplicates
+    // dropped, and rd_batch_results only copies them.  ord_ok: the buffers exist (Davis shape); ord_run: the run in
+    // flight used it; ord_off: an input overflowed its per-stream buckets - unordered kernels + host ordering until
+    // the next upload.
+    rd_ord_bufs ord;
+    bool ord_ok = false, ord_run = false, ord_off = false;
+    uint32_t bucket_limit = RD_BUCKET;
+    size_t cnt_stride = RD_CNT_TOTAL;  // words per counter set (the per-stream match counters live behind the counters)
 };
 
 static rd_layout batch_layout(const rd_batch *b) {
@@ -318,7 +326,7 @@ extern "C" int rd_batch_create(const rd_config *cfg, int n_streams, int n_blocks
     return RD_OK;
 }
 
-static uint32_t *batch_cnt(const rd_batch *b) { return b->d_cnt + (size_t)b->cnt_set * RD_CNT_TOTAL; }
+static uint32_t *batch_cnt(const rd_batch *b) { return b->d_cnt + (size_t)b->cnt_set * b->cnt_stride; }
 
 // A handle is tied to the device that was current when its buffers were allocated; every entry point
 // makes that device current for the calling thread first (handles may be used from several threads).
@@ -349,8 +357,29 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));
     HIPCHK(hipMalloc(&b->d_bits, runs * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_fix, (size_t)b->fix_cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&b->d_cnt, 2 * RD_CNT_TOTAL * sizeof(uint32_t)));
-    HIPCHK(hipMemset(b->d_cnt, 0, 2 * RD_CNT_TOTAL * sizeof(uint32_t)));
+    // ordered tail: Davis shape only (the kernels are compiled for it); RD_TAIL_IMPL=legacy switches it off (A/B),
+    // RD_TEST_BUCKET_CAP makes the buckets small so that the fallback runs on ordinary inputs (test hook)
+    {
+        const char *ti = getenv("RD_TAIL_IMPL");
+        const bool legacy = (ti && ti[0] == 'l') || getenv("RD_SLICE_IMPL");  // (an explicit slice form means the unordered kernels)
+        b->ord_ok = !legacy && b->fast_ok && b->dc.S == 14 && b->dc.P == 16 && b->dc.K == 80 && b->dc.pre_mask == 0x91D3ull &&
+                    b->n_samples < (1l << 30) && b->dc.B < (1 << 24);
+        if (const char *e = getenv("RD_TEST_BUCKET_CAP")) {
+            const long v = atol(e);
+            if (v >= 1 && v < RD_BUCKET) b->bucket_limit = (uint32_t)v;
+        }
+    }
+    b->cnt_stride = RD_CNT_TOTAL + (b->ord_ok ? (((size_t)b->n_streams + 3) & ~(size_t)3) : 0);
+    HIPCHK(hipMalloc(&b->d_cnt, 2 * b->cnt_stride * sizeof(uint32_t)));
+    HIPCHK(hipMemset(b->d_cnt, 0, 2 * b->cnt_stride * sizeof(uint32_t)));
+    if (b->ord_ok) {
+        const size_t ns = (size_t)b->n_streams;
+        HIPCHK(hipMalloc(&b->ord.smatch, ns * RD_BUCKET * sizeof(int32_t)));
+        HIPCHK(hipMalloc(&b->ord.tasks, ns * 2 * RD_BUCKET * RD_OTASK_BYTES));
+        HIPCHK(hipMalloc(&b->ord.skept, ns * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&b->ord.soff, ns * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&b->ord.wgtot, ((ns + 7) / 8) * sizeof(uint32_t)));
+    }
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
     HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
@@ -371,6 +400,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
+        hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.skept); hipFree(b->ord.soff); hipFree(b->ord.wgtot);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
@@ -397,6 +427,7 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
         return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu bytes, expected %zu", nbytes, b->iq_bytes);
     }
     HIPCHK(hipMemcpy(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice));
+    b->ord_off = false;  // a new input: the ordered tail gets its chance again
     return RD_OK;
 }
 
@@ -404,15 +435,26 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
 static int batch_search_slice(rd_batch *b, hipStream_t st) {
     const rd_layout lay = batch_layout(b);
     const long B = b->dc.B, L = b->dc.L;
-    rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
-                     b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
-    if (b->run_timing && b->run_detail) HIPCHK(hipEventRecord(b->ev[3], st));
     // the run's last kernel carries the end-of-run event itself when nothing follows it
     hipEvent_t last = b->run_timing ? b->ev[4] : b->kdone;
     const bool last_on_slice = !b->parse;
-    b->dense = rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1,
-                               b->n_blocks, 0, b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr,
-                               b->d_tasks);
+    b->ord_run = false;
+    if (b->ord_ok && !b->ord_off && !(b->run_timing && b->run_detail)) {
+        rd_ord_bufs ob = b->ord;
+        ob.scount = batch_cnt(b) + RD_CNT_TOTAL;
+        b->ord_run = rd_launch_tail_ordered(lay, b->d_bits, b->bits_stride, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
+                                            b->dc, b->n_blocks, ob, b->bucket_limit, b->d_recs, b->rec_cap, batch_cnt(b), st,
+                                            last_on_slice ? last : nullptr) != 0;
+        if (b->ord_run) b->dense = 1;  // one record per task from index 0 - and already in the final order
+    }
+    if (!b->ord_run) {
+        rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
+                         b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
+        if (b->run_timing && b->run_detail) HIPCHK(hipEventRecord(b->ev[3], st));
+        b->dense = rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1,
+                                   b->n_blocks, 0, b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr,
+                                   b->d_tasks);
+    }
     if (b->parse) {
         if (!b->d_parsed) HIPCHK(hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed)));
         rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st, b->dense);
@@ -426,7 +468,7 @@ static int batch_search_slice(rd_batch *b, hipStream_t st) {
     HIPCHK(hipStreamWaitEvent(b->copy_stream, last, 0));
     HIPCHK(hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
                           b->copy_stream));
-    const uint32_t spec = std::min(b->match_cap, b->spec_recs);
+    const uint32_t spec = std::min(b->ord_run ? b->rec_cap : b->match_cap, b->spec_recs);
     if (spec)
         HIPCHK(hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
                               b->copy_stream));
@@ -448,7 +490,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     b->fetched = false;
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;
-    uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * RD_CNT_TOTAL;
+    uint32_t *cnt = batch_cnt(b), *cnt_next = b->d_cnt + (size_t)(b->cnt_set ^ 1) * b->cnt_stride;
     b->run_timing = b->timing;  // set_timing between run() and results() does not touch the run in flight
     b->run_detail = b->timing_detail;
     if (b->timing) {
@@ -468,7 +510,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
     }
-    rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st);
+    rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
     rc = batch_search_slice(b, st);
     if (rc) return rc;
@@ -498,7 +540,17 @@ static int batch_finish(rd_batch *b) {
         } else if (attempt == 0) {
             b->last_fix = b->h_cnt[RD_CNT_FIX];
         }
-        if (b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
+        if (b->ord_run && b->h_cnt[RD_CNT_OVF]) {
+            // a stream with more matches than its bucket holds (or more records than the list): this input goes
+            // through the unordered kernels and the host-side ordering, now and until the next upload
+            b->ord_off = true;
+            const uint32_t zero[5] = {0, 0, 0, 0, 0};  // matches, boundary records, tasks, parsed, overflow
+            HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
+            int rc2 = batch_search_slice(b, st);
+            if (rc2) return rc2;
+            continue;
+        }
+        if (!b->ord_run && b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
             // every pointer is cleared as it is freed: should one of the allocations below fail, rd_batch_destroy
             // must not free anything twice (and the handle reports the failure on every later call)
             hipFree(b->d_matches); b->d_matches = nullptr;
@@ -546,7 +598,7 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     // sparse layout: one slot per match + the block-boundary twins behind match_cap; dense: one record per task
     const uint32_t nprim = b->dense ? std::min(b->h_cnt[RD_CNT_TASKS], b->rec_cap) : std::min(b->h_cnt[RD_CNT_MATCH], b->match_cap);
     const uint32_t nextra = b->dense ? 0u : std::min(b->h_cnt[RD_CNT_REC], b->match_cap);
-    const uint32_t have = std::min(b->match_cap, b->spec_recs);
+    const uint32_t have = std::min(b->ord_run ? b->rec_cap : b->match_cap, b->spec_recs);
     // Late copies go to the copy stream: it has already waited for this run's last kernel, whereas the
     // launch stream may hold the NEXT batch's run by now (two resident batches alternate in bench.py) and a
     // copy queued there would wait for it.
@@ -561,6 +613,18 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     const uint32_t nrec = nprim + nextra;
     b->spec_recs = std::max<uint32_t>(1024, nprim + nprim / 4);
     const double t2 = now_ms();
+    if (b->ord_run) {  // the device wrote them in the reference's order, duplicates dropped: copy, nothing else
+        *n = (int)nrec;
+        if ((int)nrec > cap) return fail(RD_ERR_CAPACITY, "need room for %u packets", nrec);
+        if (nrec) {
+            if (!out) return fail(RD_ERR_ARG, "null out");
+            memcpy(out, b->h_recs_pin, (size_t)nrec * sizeof(rd_packet));
+        }
+        if (dbg_host())
+            fprintf(stderr, "[rd] results (ordered tail): finish %.3f ms, D2H %u recs %.3f ms, copy %.3f ms\n", t1 - t0, nrec,
+                    t2 - t1, now_ms() - t2);
+        return RD_OK;
+    }
     order_and_dedupe(b->h_recs_pin, nrec, b->dc.S, b->order);
     const std::vector<uint32_t> &kept = b->order.kept;
     *n = (int)kept.size();

@@ -123,8 +123,10 @@ __device__ __forceinline__ uint32_t rd_lds_addr(const void *p) {
 }
 
 struct rd_mf_state {
-    uint32_t W;       // sign bits, first sample at the top (reversed at the end)
+    uint32_t W;       // sign bits of blocks 1-3 (24), first sample at the top
+    uint32_t w0;      // the six own sign bits of block 0
     uint32_t fbytes;  // byte b != 0: block b's group is inside the guard band
+    bool slow;        // wave-uniform: some block of the tile took the second-level test (fbytes may be set)
     float g0r, g0i;   // block 0's first output: its two boundary numerators come last
 };
 
@@ -149,14 +151,14 @@ __device__ __forceinline__ void rd_mf_burst(const rd_h8 (&Ahi)[3], const rd_h8 (
     // the hi accumulator starts at -D_hi in all sixteen positions (four broadcast reads, in flight under
     // the fragment preparation)
     rd_f4v c0, c1, c2, c3;
-    if (DBG != 4)
+    if (DBG != 4 && DBG != 10)
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4"
                      : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(dc_addr) : "memory");
     // fragments of k-steps 2B, 2B+1, 2B+2 of the window: the first one is the previous block's last
     if (B == 0) bf[0] = rd_mf_frag(D[0]); else bf[0] = bf[2];
     bf[1] = rd_mf_frag(D[2 * B + 1]);
     bf[2] = rd_mf_frag(D[2 * B + 2]);
-    if (DBG == 4) {  // ablation: no matrix pipe, the vector work on stand-in values
+    if (DBG == 4 || DBG == 10) {  // ablation: no matrix pipe, the vector work on stand-in values
         const rd_u4v q0 = __builtin_bit_cast(rd_u4v, bf[0]), q1 = __builtin_bit_cast(rd_u4v, bf[1]),
                      q2 = __builtin_bit_cast(rd_u4v, bf[2]);
 #pragma unroll
@@ -199,20 +201,27 @@ __device__ __forceinline__ void rd_mf_tail(const float (&g)[16], uint32_t xw, ui
     rd_f4v p = {0.0f, 0.0f, 0.0f, 0.0f};
     if (B > 0) p = rd_lds_read16<0>(xr);  // g[base-1], g[base]: in flight under the group's own work
     float nmin = 3.0e38f, tmax = 0.0f;
-    uint32_t w6 = 0;
+    float num[6];  // the six numerators of this lane's own outputs
 #pragma unroll
     for (int q = 2; q < 8; q += 2) {
         float ta, tb;
-        const float na = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1], ta);
-        const float nb = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1], tb);
-        nmin = rd_min3abs(nmin, na, nb);
+        num[q - 2] = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1], ta);
+        num[q - 1] = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1], tb);
+        nmin = rd_min3abs(nmin, num[q - 2], num[q - 1]);
         tmax = rd_max3abs(tmax, ta, tb);
-        w6 = rd_shift_in_sign(w6, na);
-        w6 = rd_shift_in_sign(w6, nb);
     }
+    // Signs: ONE shift chain per word, in time order, one v_alignbit per sample and nothing else (separate
+    // partial words shifted and OR-ed together afterwards cost three more instructions per block, and every
+    // instruction that is not an f32 multiply / add costs a SIMD 4.5 cycles here).  Blocks 1-3 go into st.W
+    // behind the wait for their predecessors; block 0's own six go into st.w0 and are completed, with the two
+    // numerators that need the previous column's last outputs, at the end of the tile.
     if (B == 0) {
-        st.g0r = g[0]; st.g0i = g[1];  // its two boundary numerators follow at the end of the tile
-        st.W = w6;
+        st.g0r = g[0]; st.g0i = g[1];
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) w = rd_shift_in_sign(w, num[i]);
+        st.w0 = w;
+        st.W = 0;
     } else {
         rd_lds_wait(p);
         float t0, t1;
@@ -220,13 +229,16 @@ __device__ __forceinline__ void rd_mf_tail(const float (&g)[16], uint32_t xw, ui
         const float n1 = rd_mf_num(p.z, p.w, g[0], g[1], t1);
         nmin = rd_min3abs(nmin, n0, n1);
         tmax = rd_max3abs(tmax, t0, t1);
-        uint32_t w2 = rd_shift_in_sign(0u, n0);
-        w2 = rd_shift_in_sign(w2, n1);
-        st.W = (st.W << 8) | (w2 << 6) | w6;
+        uint32_t w = rd_shift_in_sign(st.W, n0);
+        w = rd_shift_in_sign(w, n1);
+#pragma unroll
+        for (int i = 0; i < 6; i++) w = rd_shift_in_sign(w, num[i]);
+        st.W = w;
     }
     if (DBG == 0 || DBG == 3) {
         const float nm = rd_mf_guard(nmin, tmax);
         if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {  // rare; NaN counts as inside
+            st.slow = true;
             float F = 0.0f;
 #pragma unroll
             for (int r = 0; r < 8; r++) F = rd_max3abs(F, g[2 * r], g[2 * r + 1]);
@@ -251,7 +263,7 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     __builtin_amdgcn_sched_barrier(0);
     rd_mf_burst<B, DBG>(Ahi, Alo, D, bf, dc_addr, ah, al);
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG == 5) {  // ablation: the matrix pipe with next to no vector work behind it
+    if (DBG == 5 || DBG == 11) {  // ablation: the matrix pipe with next to no vector work behind it
         st.W ^= __builtin_bit_cast(uint32_t, ah[0] + al[15]);
         return;
     }
@@ -335,10 +347,14 @@ struct rd_mf_nextchunk {
 };
 __device__ __forceinline__ rd_mf_nextchunk rd_mf_chunk_at(uint64_t chunk_id, uint32_t chunk, uint32_t tps, uint32_t total) {
     rd_mf_nextchunk c;
-    const uint64_t nt = chunk_id * chunk;
-    c.tile = nt < total ? (uint32_t)nt : 0xFFFFFFFFu;
+    // 32-bit scalar arithmetic (a 64-bit compare of two scalars compiles to a VECTOR compare): a chunk id at or
+    // past the number of chunks means "none"; below it, chunk_id * chunk < total + chunk fits (total < 2^32 - 2^16)
+    const uint32_t n_chunks = (total + chunk - 1) / chunk;
+    const bool have = chunk_id < n_chunks;
+    const uint32_t nt = have ? (uint32_t)chunk_id * chunk : 0u;
+    c.tile = have ? nt : 0xFFFFFFFFu;
     c.s = 0; c.ti = 0;
-    if (nt < total) {  // (the one division per chunk: done at the loop top, where few registers are live)
+    if (have) {  // (the one division per chunk: done at the loop top, where few registers are live)
         c.s = __builtin_amdgcn_readfirstlane(c.tile / tps);
         c.ti = c.tile - c.s * tps;
     }
@@ -397,7 +413,7 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 // DBG: 0 product; 3 also dumps g (dbg_g[tile][2048][2], sample order; the test hook).  Diagnostic library only
 // (-DRD_DIAG, librtldavis_hip_diag.so; garbage results): 1 no global loads; 2 loads + LDS reads + stores only;
 // 4 = 1 without the MFMAs; 5 = 1 with the MFMAs and almost no vector work; 6 loads only; 7 no guard band;
-// 9 = 16 of the 24 MFMAs per tile.
+// 9 = 16 of the 24 MFMAs per tile; 10 = 4 with the loads; 11 = 5 with the loads.
 // OPT (compile time): RD_OPT_PIPE block B+1's MFMAs before block B's vector work; RD_OPT_HALO the 16 bytes in front
 // of a tile come from the previous tile's registers inside a chunk (four LDS-DMA instructions per tile, not five);
 // RD_OPT_STAMP (diagnostic library) s_memtime stamps, per-wave sums in dbg_g.
@@ -566,16 +582,17 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         if (STAMP) { sm_mark = rd_stamp(); sm_gap += sm_mark - sm_b; }
 
         uint32_t word = 0, fbytes = 0;
+        bool slow_taken = false;
         if (DBG == 2 || DBG == 6) {
 #pragma unroll
             for (int j = 0; j < 9; j++) word ^= D[j].x ^ D[j].y;
         } else {
             rd_h8 bf[3];
             rd_mf_state stt;
-            stt.W = 0; stt.fbytes = 0; stt.g0r = 0.0f; stt.g0i = 0.0f;
+            stt.W = 0; stt.w0 = 0; stt.fbytes = 0; stt.slow = false; stt.g0r = 0.0f; stt.g0i = 0.0f;
             float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 8 * h + 1) * 2 : nullptr;
             const int dleft = RD_TILE_SAMPLES - (64 * n + 8 * h + 1);  // outputs of this lane inside the tile
-            if ((OPT & RD_OPT_PIPE) && DBG != 5) {
+            if ((OPT & RD_OPT_PIPE) && DBG != 5 && DBG != 11) {
                 // block B+1's burst is issued before block B's tail: the tail's vector work has no use for the
                 // matrix pipe's results and runs under the MFMAs (the scheduler is free to interleave them; the
                 // fences only keep a burst behind the combine that frees its accumulator registers)
@@ -613,11 +630,15 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
                 float t0, t1;
                 const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, t0);
                 const float n1 = rd_mf_num(p.z, p.w, stt.g0r, stt.g0i, t1);
-                stt.W |= __builtin_bit_cast(uint32_t, n0) & 0x80000000u;
-                stt.W |= (__builtin_bit_cast(uint32_t, n1) >> 1) & 0x40000000u;
+                // byte 0 of the word: (n0, n1, block 0's six), on top of the 24 bits of blocks 1-3
+                uint32_t b0 = rd_shift_in_sign(0u, n0);
+                b0 = rd_shift_in_sign(b0, n1);
+                b0 = (b0 << 6) | stt.w0;
+                stt.W = (b0 << 24) | stt.W;
                 if (DBG == 0 || DBG == 3) {
                     const float nm = rd_mf_guard(rd_min3abs(3.0e38f, n0, n1), rd_max3abs(0.0f, t0, t1));
                     if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {
+                        stt.slow = true;
                         float F = rd_max3abs(0.0f, p.x, p.y);
                         F = rd_max3abs(F, p.z, p.w);
                         F = rd_max3abs(F, stt.g0r, stt.g0i);
@@ -629,6 +650,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
             xw3 ^= wtoggle;
             word = __builtin_bitreverse32(stt.W);  // byte b = the signs of block b's group
             fbytes = stt.fbytes;
+            slow_taken = stt.slow;
         }
         // The lane holds bytes (groups) 2b + h of its column's two words: gather word h of the column
         // (lanes n and n + 32 exchange halves), the flags likewise.
@@ -640,15 +662,16 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         const bool carry = inchunk > 0 && ti > 0;  // previous iteration = previous tile of this stream
         const uint32_t run = ti * 64 + 2 * n + h;  // word index in the stream
         const uint32_t t0 = run * RD_RUN;
-        const bool any_flag = rd_mf_any(fbytes != 0);
+        // (fbytes is only ever set inside the wave-uniform second-level branches: no ballot in the common case)
+        const bool any_flag = slow_taken && rd_mf_any(fbytes != 0);
         if (any_flag) {  // wave-uniform, rare
             const auto f2 = __builtin_amdgcn_permlane32_swap(fbytes, fbytes, false, false);
             const uint32_t fb = __builtin_amdgcn_perm(f2[1], f2[0], psel);
             gmask = ((fb * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
         }
-        if (lane == 0) {
+        if (!carry && lane == 0) {  // (the scalar test first: one tile in sixteen)
             if (ti == 0 && !lay.hist_mode) gmask = 0xFu;  // zero history: first run exact
-            else if (!carry) gmask |= 1u;                 // no predecessors for the tile's first group
+            else gmask |= 1u;                             // no predecessors for the tile's first group
         }
         const bool ragged = (ti + 1 == tiles_per_stream) && (lay.n_samples % RD_TILE_SAMPLES) != 0;
         if (DBG == 6) {
@@ -842,7 +865,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     }
 #ifdef RD_DIAG
     const rd_mf_params &P = rd_mf_get_params();
-    const int key = P.dbg * 100 + P.nbuf * 10 + P.opt;
+    const int key = P.dbg * 100 + P.nbuf * 10 + P.opt;  // (opt < 8)
     switch (key) {
 #define RD_V(D, NB, O) case (D) * 100 + (NB) * 10 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
         RD_V(0, 1, 0) RD_V(0, 1, 1) RD_V(0, 1, 2) RD_V(0, 1, 3) RD_V(0, 1, 4) RD_V(0, 1, 5) RD_V(0, 1, 6) RD_V(0, 1, 7)
@@ -851,6 +874,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
         RD_V(6, 1, 0) RD_V(6, 1, 2) RD_V(6, 1, 4) RD_V(6, 1, 6)
         RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
         RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
+        RD_V(10, 1, 0) RD_V(10, 1, 4) RD_V(11, 1, 0) RD_V(11, 1, 4)
         RD_V(0, 2, 0)
 #undef RD_V
         default:

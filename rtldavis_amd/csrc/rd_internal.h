@@ -8,7 +8,9 @@
 // counters[] slots (device uint32)
 // FIX: flagged runs; MATCH: preamble matches (= primary records); REC: second records of
 // block-boundary positions; PARSED: CRC-valid messages
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_SLOTS = 8 };
+// OVF: the ordered tail could not hold this input (bit 0: a stream with more than RD_BUCKET matches, bit 1: more
+// records than the list has room for)
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_OVF = 5, RD_CNT_SLOTS = 8 };
 // Behind the RD_CNT_SLOTS counters the host reads back: the demod kernel's work queues (chunks handed out beyond
 // the first one of every wave).  One counter word sustains ~90 atomics per microsecond, so there are RD_NQUEUE of
 // them, 256 bytes apart; wave w draws from queue w % RD_NQUEUE, which owns the chunks nwaves + q + RD_NQUEUE k.
@@ -60,12 +62,29 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
+// zero_words: how many words at zero_next (the counter set, plus the per-stream match counters of the ordered tail
+// when the handle has them behind it)
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
-                     uint32_t *zero_next, hipStream_t st);
+                     uint32_t *zero_next, hipStream_t st, uint32_t zero_words = RD_CNT_TOTAL);
 // Search positions p in [p_lo, p_hi] of every stream's bit array (bits outside [0, n_bits) are 0).
+// smatch / scount (both or neither): the matches go to per-stream buckets instead of the one list (ordered tail)
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
-                      hipStream_t st);
+                      hipStream_t st, int32_t *smatch = nullptr, uint32_t *scount = nullptr);
+// The ordered tail of the batch path (rd_kernels.hip): search into per-stream buckets, per-stream rank and dedupe,
+// RSSI / SNR, records written in the reference's order.  RD_BUCKET matches per stream at most.
+#define RD_BUCKET 32
+#define RD_OTASK_BYTES 32
+struct rd_ord_bufs {
+    int32_t *smatch = nullptr;   // [n_streams][RD_BUCKET] positions
+    uint32_t *scount = nullptr;  // [n_streams] matches found (lives behind the counter set of the run: cleared with it)
+    void *tasks = nullptr;       // [n_streams][2 RD_BUCKET] entries of RD_OTASK_BYTES
+    uint32_t *skept = nullptr, *soff = nullptr;  // [n_streams] surviving tasks, their offset inside the workgroup of 8 streams
+    uint32_t *wgtot = nullptr;   // [(n_streams + 7) / 8] surviving tasks per workgroup
+};
+int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
+                           const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
+                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop = nullptr);
 // Slice + RSSI/SNR, one wave per match.  batch_mode = 1: position = absolute sample, calls derived
 // from it (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
 // lay.iq points at the newest block's first sample.

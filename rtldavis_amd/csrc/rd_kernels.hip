@@ -273,10 +273,10 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_stream, const uint32_t *fix_list,
                                                uint32_t fix_cap, const uint32_t *counters, int all,
-                                               uint32_t *zero_next) {
+                                               uint32_t *zero_next, uint32_t zero_words) {
     // the counters of the handle's NEXT run (double-buffered) are cleared here, saving a memset launch
     if (zero_next && blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < RD_CNT_TOTAL; i += blockDim.x) zero_next[i] = 0;
+        for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x) zero_next[i] = 0;
     uint64_t count;
     if (all) {
         count = (uint64_t)lay.n_streams * runs_per_stream;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
 }
 
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
-                     uint32_t *zero_next, hipStream_t st) {
+                     uint32_t *zero_next, hipStream_t st, uint32_t zero_words) {
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
     if (rps == 0 || lay.n_streams == 0) return;
     uint64_t want = all ? (uint64_t)lay.n_streams * rps : fix_cap;
@@ -341,7 +341,7 @@ void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fi
     if (wgs > 256ull * 16) wgs = 256ull * 16;
     if (wgs == 0) wgs = 1;
     hipLaunchKernelGGL(k_fixup, dim3((unsigned)wgs), dim3(256), 0, st, lay, rps, fix_list, fix_cap, counters, all,
-                       zero_next);
+                       zero_next, zero_words);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -391,11 +391,13 @@ __device__ __forceinline__ void rd_flush_matches(const rd_match *pend, uint32_t 
 
 // S_ > 0: compile-time symbol length / preamble length (register funnel with constant
 // shifts); S_ == 0: run-time cfg.S / cfg.P (words fetched per tap).
-template <int S_, int P_, uint64_t PRE_>
+// BKT: the matches of stream s go to smatch[s][slot], slot drawn from scount[s] (one counter per stream: the ordered
+// tail, k_classify_ord, takes one lane per slot); nothing is staged and nothing is left to flush at the end.
+template <int S_, int P_, uint64_t PRE_, bool BKT = false>
 __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
                                                 long base, long groups_per_stream, long p_lo, long p_hi,
                                                 rd_devcfg cfg, rd_match *matches, uint32_t match_cap,
-                                                uint32_t *counters) {
+                                                uint32_t *counters, int32_t *smatch = nullptr, uint32_t *scount = nullptr) {
     __shared__ rd_match pend_all[RD_SEARCH_WAVES][RD_MATCH_PEND];
     const int lane = threadIdx.x & 63;
     rd_match *pend = pend_all[threadIdx.x >> 6];
@@ -511,6 +513,20 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
             for (int o = 0; o < RD_SEARCH_OUT; o++) {
                 uint32_t mm = m[o];
                 uint64_t any = __ballot(mm != 0);
+                while (BKT && any) {  // (s is wave-uniform: one atomic per round)
+                    const uint32_t nf = (uint32_t)__popcll(any);
+                    uint32_t slot0 = 0;
+                    if (lane == 0) slot0 = atomicAdd(&scount[s], nf);
+                    slot0 = __builtin_amdgcn_readfirstlane(slot0);
+                    if (mm) {
+                        const int bpos = __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const uint32_t slot = slot0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32),
+                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0));
+                        if (slot < RD_BUCKET) smatch[(size_t)s * RD_BUCKET + slot] = (int32_t)(p0 + 32 * o + bpos);
+                    }
+                    any = __ballot(mm != 0);
+                }
                 while (any) {  // each round, every lane with matches left contributes its lowest one
                     const uint32_t nf = (uint32_t)__popcll(any);
                     if (npend + nf > RD_MATCH_PEND) {
@@ -535,6 +551,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
     // End of kernel: the workgroup's leftovers leave through ONE atomic (every wave flushing
     // its own few entries made 8192 serialized atomics = 90 us of a 110 us kernel).  What is
     // left is issue-bound: 64 funnel shifts (v_alignbit_b32, 4-cycle class) per 128 positions.
+    if (BKT) return;
     __shared__ uint32_t left[RD_SEARCH_WAVES + 1];
     if (lane == 0) left[threadIdx.x >> 6] = npend;
     __syncthreads();
@@ -564,7 +581,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
 
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
-                      hipStream_t st) {
+                      hipStream_t st, int32_t *smatch, uint32_t *scount) {
     if (p_hi < p_lo || n_streams == 0) return;
     const long base = (p_lo >> 5) << 5;  // floor to a word boundary (p_lo may be negative)
     const long nwords = (n_bits + 31) / 32;
@@ -575,7 +592,10 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
     if (wgs > 256ull * cap) wgs = 256ull * cap;
     // the Davis configuration (protocol.py:68-76): 14 samples/symbol, preamble 1100101110001001
     // (bit m of the mask = symbol m -> 0x91D3)
-    if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
+    if (smatch && scount && cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
+        hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull, true>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
+                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, smatch, scount);
+    else if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
         hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
                            n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
     else
@@ -1138,6 +1158,225 @@ __global__ __launch_bounds__(256) void k_rssi_u8(rd_layout lay, rd_devcfg cfg, c
         }
         if (lane == 0) { recs[rec].rssi = rssi; recs[rec].snr = snr; }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The ordered tail (batch path, Davis shape): the records leave the device in the reference's order, per-call
+// duplicates already dropped - what rd_batch_results used to do on one host core (0.23 ms per batch: radix sort by
+// (stream, call, index % S, index), then the first-occurrence-wins dedupe of py:203-205).
+//   k_search<.., BKT>  : the matches of stream s land in smatch[s][0 .. scount[s])
+//   k_classify_ord     : 32 lanes per stream, one per match: call assignment and packet bytes as in k_classify, then -
+//                        every task of the stream sits in the same half-wave - the exact dedupe and the rank of each
+//                        surviving task by two short loops of lane broadcasts; per-stream counts, their prefix inside
+//                        the workgroup and the workgroup's total
+//   k_rssi_ord         : one wave per stream: adds the totals of the workgroups in front of its own (at most
+//                        n_streams / 8 words), evaluates the RSSI / SNR windows of its tasks on the matrix pipe as
+//                        k_rssi_u8 does and writes each whole record at its final position
+// A stream with more than RD_BUCKET matches (or more records than the list holds) raises RD_CNT_OVF and the host
+// falls back to the unordered kernels above for that input.
+// ------------------------------------------------------------------------------------------
+struct rd_otask {   // 32 bytes
+    int32_t call, q;
+    uint32_t d[3];  // the packet's bytes (K_ = 80: ten of them)
+    uint32_t pad[3];
+};
+
+template <int S_, int K_>
+__global__ __launch_bounds__(256) void k_classify_ord(const uint32_t *bits, size_t bits_stride, int nwords, rd_devcfg cfg,
+                                                      const int32_t *smatch, const uint32_t *scount, int n_streams,
+                                                      uint32_t bucket_limit, int n_calls, rd_otask *tasks, uint32_t *skept,
+                                                      uint32_t *soff, uint32_t *wgtot, uint32_t rec_cap, uint32_t *counters) {
+    constexpr int NBITS = (K_ - 1) * S_ + 1;          // bits pos .. of the packet
+    constexpr int NU = (NBITS + 31) / 32;
+    constexpr int NW = NU + 1;
+    constexpr int NBYTES = (K_ + 7) / 8;
+    static_assert(K_ % 8 == 0 && NBYTES <= 12, "at most 12 packet bytes in a task entry");
+    __shared__ uint32_t s_k[8], s_m[8];
+    const int lane = threadIdx.x & 63, sub = lane & 31, grp = threadIdx.x >> 5;
+    const int stream = blockIdx.x * 8 + grp;
+    uint32_t count = stream < n_streams ? scount[stream] : 0u;
+    const uint32_t nmatch = count;
+    const bool ovf = count > bucket_limit;
+    if (ovf) count = 0;  // the host runs the unordered path on this input
+    const bool live = (uint32_t)sub < count;
+    int pos = 0;
+    if (live) pos = smatch[(size_t)stream * RD_BUCKET + sub];
+    // calls that report this position (py:194, q <= B), as in k_classify
+    const uint32_t pl = (uint32_t)(pos + cfg.L), bq = pl / (uint32_t)cfg.B, br = pl - bq * (uint32_t)cfg.B;
+    const int b0 = (int)bq - 1;
+    const int q0 = pos - ((b0 + 1) * cfg.B - cfg.L);
+    const bool ok0 = live && b0 >= 0 && b0 < n_calls;
+    const int b1 = b0 - 1, q1 = q0 + cfg.B;
+    const bool ok1 = live && br == 0 && b1 >= 0 && b1 < n_calls;
+    // the packet's bytes: byte bi = symbols 8 bi .. 8 bi + 7, first symbol = MSB (py:197-200)
+    const uint32_t *w = bits + (size_t)(stream < n_streams ? stream : 0) * bits_stride;
+    const int wi0 = pos >> 5;
+    const uint32_t sh = (uint32_t)(pos & 31);
+    uint32_t W[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        const int wi = wi0 + j;
+        W[j] = (live && wi >= 0 && wi < nwords) ? w[wi] : 0u;
+    }
+    uint32_t u[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], sh);
+    uint32_t dw[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < K_; k++) {
+        const int bit = k * S_, bi = k >> 3;
+        const uint32_t b = (u[bit >> 5] >> (bit & 31)) & 1u;
+        dw[bi >> 2] |= b << (8 * (bi & 3) + 7 - (k & 7));
+    }
+    // keys: (call, phase, q), the order of py:171-188 inside a call; task 0 = (b0, q0), task 1 = (b0 - 1, q0 + B)
+    const uint32_t ph0 = (uint32_t)q0 % (uint32_t)S_, ph1 = (uint32_t)q1 % (uint32_t)S_;
+    const uint32_t k0 = (ph0 << 24) | (uint32_t)q0, k1 = (ph1 << 24) | (uint32_t)q1;  // q <= B < 2^24 (checked by the host)
+    uint32_t maxc = count;
+    maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, 32, 64));
+    maxc = __builtin_amdgcn_readfirstlane(maxc);
+    const int src0 = lane & 32;
+    // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205)
+    bool dup0 = false, dup1 = false;
+    for (uint32_t j = 0; j < maxc; j++) {
+        const int src = src0 + (int)j;
+        const uint32_t oflags = (uint32_t)__shfl((int)((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)), src, 64);
+        const int ob0 = __shfl(b0, src, 64);
+        const uint32_t ok0_ = (uint32_t)__shfl((int)k0, src, 64), ok1_ = (uint32_t)__shfl((int)k1, src, 64);
+        const bool same = (uint32_t)__shfl((int)dw[0], src, 64) == dw[0] && (uint32_t)__shfl((int)dw[1], src, 64) == dw[1] &&
+                          (uint32_t)__shfl((int)dw[2], src, 64) == dw[2];
+        if (same) {
+            if ((oflags & 1u) && ob0 == b0 && ok0_ < k0) dup0 = true;
+            if ((oflags & 2u) && ob0 - 1 == b0 && ok1_ < k0) dup0 = true;
+            if ((oflags & 1u) && ob0 == b1 && ok0_ < k1) dup1 = true;
+            if ((oflags & 2u) && ob0 - 1 == b1 && ok1_ < k1) dup1 = true;
+        }
+    }
+    const bool kept0 = ok0 && !dup0, kept1 = ok1 && !dup1;
+    // pass 2: rank among the surviving tasks of the stream
+    uint32_t r0 = 0, r1 = 0;
+    for (uint32_t j = 0; j < maxc; j++) {
+        const int src = src0 + (int)j;
+        const uint32_t oflags = (uint32_t)__shfl((int)((kept0 ? 1u : 0u) | (kept1 ? 2u : 0u)), src, 64);
+        const int ob0 = __shfl(b0, src, 64);
+        const uint32_t ok0_ = (uint32_t)__shfl((int)k0, src, 64), ok1_ = (uint32_t)__shfl((int)k1, src, 64);
+        auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
+        if (oflags & 1u) { r0 += before(ob0, ok0_, b0, k0) ? 1u : 0u; r1 += before(ob0, ok0_, b1, k1) ? 1u : 0u; }
+        if (oflags & 2u) { r0 += before(ob0 - 1, ok1_, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, ok1_, b1, k1) ? 1u : 0u; }
+    }
+    const uint64_t m0 = __ballot(kept0), m1 = __ballot(kept1);
+    const uint32_t kept = (uint32_t)__popc((uint32_t)(m0 >> src0)) + (uint32_t)__popc((uint32_t)(m1 >> src0));
+    rd_otask *tk = tasks + (size_t)(stream < n_streams ? stream : 0) * (2 * RD_BUCKET);
+    if (kept0) { rd_otask t = {b0, q0, {dw[0], dw[1], dw[2]}, {0, 0, 0}}; tk[r0] = t; }
+    if (kept1) { rd_otask t = {b1, q1, {dw[0], dw[1], dw[2]}, {0, 0, 0}}; tk[r1] = t; }
+    if (sub == 0) { s_k[grp] = kept; s_m[grp] = nmatch; }
+    if (ovf && sub == 0) atomicOr(&counters[RD_CNT_OVF], 1u);
+    __syncthreads();
+    if (sub == 0 && stream < n_streams) {
+        uint32_t off = 0;
+        for (int g = 0; g < grp; g++) off += s_k[g];
+        skept[stream] = kept;
+        soff[stream] = off;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, mt = 0;
+        for (int g = 0; g < 8; g++) { tot += s_k[g]; mt += s_m[g]; }
+        wgtot[blockIdx.x] = tot;
+        if (tot) {
+            const uint32_t before = atomicAdd(&counters[RD_CNT_TASKS], tot);
+            if (before + tot > rec_cap) atomicOr(&counters[RD_CNT_OVF], 2u);
+        }
+        if (mt) atomicAdd(&counters[RD_CNT_MATCH], mt);
+    }
+}
+
+// One wave per stream; the tasks of a stream are consecutive entries, so the next task's window bytes are fetched
+// while the current one runs on the matrix pipe (as in k_rssi_u8).
+__global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, const rd_otask *tasks, const uint32_t *skept,
+                                                  const uint32_t *soff, const uint32_t *wgtot, int n_streams, int nbytes,
+                                                  rd_packet *recs, uint32_t rec_cap, const uint32_t *counters) {
+    const int lane = threadIdx.x & 63;
+    const int stream = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (stream >= n_streams) return;
+    if (counters[RD_CNT_OVF]) return;  // the host discards this run's records
+    const uint32_t n = skept[stream];
+    if (n == 0) return;
+    rd_k_h8 Ahi[3], Alo[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
+        Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
+    }
+    // records in front of this stream: the workgroups of k_classify_ord before its own, then its place inside
+    uint32_t part = 0;
+    const int wg = stream >> 3;
+    for (int i = lane; i < wg; i += 64) part += wgtot[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(part) + soff[stream];
+    rd_stream_view v;
+    v.base = lay.iq + (size_t)stream * lay.stream_stride;
+    v.valid_from = lay.valid_from;
+    v.n = lay.n_samples;
+    const rd_otask *tk = tasks + (size_t)stream * (2 * RD_BUCKET);
+    rd_otask t_cur = tk[0], t_nxt = n > 1 ? tk[1] : tk[0];
+    auto job_of = [&](const rd_otask &t) {
+        return rd_rssi_prepare(v, __builtin_amdgcn_readfirstlane(t.call) * cfg.B, cfg, __builtin_amdgcn_readfirstlane(t.q), lane);
+    };
+    rd_rssi_job j_cur = job_of(t_cur);
+    rd_rssi_data d_cur = {};
+    if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+    for (uint32_t r = 0; r < n; r++) {
+        const rd_otask t_now = t_cur;
+        const rd_rssi_job j_now = j_cur;
+        const rd_rssi_data d_now = d_cur;
+        if (r + 1 < n) {
+            j_cur = job_of(t_nxt);
+            if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+        }
+        t_cur = t_nxt;
+        if (r + 2 < n) t_nxt = tk[r + 2];
+        double rssi = 0.0, snr = 0.0;
+        const int call = __builtin_amdgcn_readfirstlane(t_now.call), q = __builtin_amdgcn_readfirstlane(t_now.q);
+        if (j_now.ok) {
+            float noise, sig;
+            rd_rssi_block(j_now, d_now, Ahi, Alo, lane, noise, sig);
+            rd_rssi_finish(noise, sig, j_now.ns, j_now.pe, j_now.q, lane, rssi, snr);
+        } else {  // a window that reaches outside the stream: the fp32 path with its per-sample checks
+            rd_rssi_u8(v, (long)call * cfg.B, cfg, (long)q, lane, rssi, snr);
+        }
+        const uint32_t at = first + r;
+        if (lane == 0 && at < rec_cap) {
+            uint4 *o = (uint4 *)&recs[at];
+            o[0] = uint4{(uint32_t)stream, (uint32_t)call, (uint32_t)q, (uint32_t)nbytes};
+            o[1] = uint4{t_now.d[0], t_now.d[1], t_now.d[2], 0u};
+            o[2] = uint4{0u, 0u, 0u, 0u};
+            recs[at].rssi = rssi;
+            recs[at].snr = snr;
+        }
+    }
+}
+
+// returns 1 when the ordered tail was launched (records: final, RD_CNT_TASKS of them from index 0), 0 when the
+// shape is not the one it is built for (the caller then uses rd_launch_search + rd_launch_slice)
+int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
+                           const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
+                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop) {
+    if (!(cfg.S == 14 && cfg.P == 16 && cfg.K == 80 && cfg.pre_mask == 0x91D3ull) || n_bits >= (1l << 30) || cfg.B >= (1 << 24) ||
+        !ob.smatch || lay.n_streams <= 0)
+        return 0;
+    rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount);
+    const uint32_t cg = (uint32_t)(lay.n_streams + 7) / 8;
+    hipLaunchKernelGGL((k_classify_ord<14, 80>), dim3(cg), dim3(256), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32), cfg,
+                       ob.smatch, ob.scount, lay.n_streams, bucket_limit < RD_BUCKET ? bucket_limit : (uint32_t)RD_BUCKET, n_calls,
+                       (rd_otask *)ob.tasks, ob.skept, ob.soff, ob.wgtot, rec_cap, counters);
+    const uint32_t rg = (uint32_t)(lay.n_streams + 3) / 4;
+    if (ev_stop)
+        hipExtLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, nullptr, ev_stop, 0, lay, cfg, (const rd_otask *)ob.tasks,
+                              ob.skept, ob.soff, ob.wgtot, lay.n_streams, cfg.nbytes, recs, rec_cap, counters);
+    else
+        hipLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_otask *)ob.tasks, ob.skept, ob.soff,
+                           ob.wgtot, lay.n_streams, cfg.nbytes, recs, rec_cap, counters);
+    return 1;
 }
 
 static uint32_t rd_slice_grid(uint32_t match_cap) {

@@ -815,3 +815,61 @@ def test_match_list_overflow_is_transparent(dsp, batchmod, golden_streams, monke
         for i, seed in enumerate(seeds):
             assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
     assert bd.counters()["matches"] > 7
+
+
+def _records_of_child(tmp_path, n_seeds, env_extra, name):
+    """The batch path's records from a fresh process (the library reads its switches once per process)."""
+    import subprocess
+    import sys
+    out = tmp_path / f"{name}.npy"
+    child = (
+        "import sys, numpy as np\n"
+        "from rtldavis_amd import batch, dsp, synth\n"
+        "cfg = dsp.PacketConfig(19200, 14, 16, 80, '1100101110001001', 8192)\n"
+        f"raw = synth.synth_streams(list(range({n_seeds})))\n"
+        f"bd = batch.BatchDemodulator(cfg, {n_seeds}, synth.BLOCKS_PER_STREAM)\n"
+        "bd.upload(raw); bd.run()\n"
+        f"np.save(r'{out}', bd.results())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", child], check=True, env=dict(os.environ, **env_extra), cwd=root, timeout=300)
+    return np.load(out)
+
+
+@pytest.mark.gpu
+def test_ordered_tail_equals_the_unordered_kernels_plus_host_ordering(dsp, batchmod, tmp_path):
+    """The batch path's default tail orders and dedupes on the device (k_search into per-stream buckets,
+    k_classify_ord, k_rssi_ord: dsp.py:171-188 order, dsp.py:203-205 first occurrence wins); RD_TAIL_IMPL=legacy is
+    the previous form - unordered kernels, radix sort and dedupe on the host.  Same records, field for field."""
+    seeds = list(range(40))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    bd.upload(raw)
+    bd.run()
+    mine = bd.results().copy()
+    other = _records_of_child(tmp_path, len(seeds), {"RD_TAIL_IMPL": "legacy"}, "legacy")
+    assert len(mine) == len(other) > 0
+    for f in ("stream", "call", "index", "nbytes"):
+        assert np.array_equal(mine[f], other[f]), f
+    assert np.array_equal(mine["data"], other["data"])
+    assert np.all(np.abs(mine["rssi"] - other["rssi"]) < 1e-3)
+    assert np.all(np.abs(mine["snr"] - other["snr"]) < 1e-3)
+    assert bd.counters()["matches"] > 0
+
+
+@pytest.mark.gpu
+def test_ordered_tail_falls_back_when_a_stream_overflows_its_bucket(dsp, batchmod, golden_streams, monkeypatch):
+    """RD_TEST_BUCKET_CAP=2: every stream has more than two matches, the ordered tail raises its overflow flag, and
+    rd_batch_results re-runs the unordered kernels on the same bits - the fixtures' packets, twice in a row (the
+    second run goes straight to the unordered path: no new upload in between), and again after a new upload."""
+    monkeypatch.setenv("RD_TEST_BUCKET_CAP", "2")
+    seeds = list(range(10))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    for _ in range(2):
+        res = bd.demodulate(raw)
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+    bd.run()
+    res = bd.packets()
+    for i, seed in enumerate(seeds):
+        assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))

@@ -18,7 +18,7 @@ uniq = synth.synth_streams(range(64))
 host = np.tile(uniq, (64, 1))
 bd = batch.BatchDemodulator(cfg, 4096, 33)
 bd.upload(host)
-bd.set_timing(2)
+bd.set_timing(int(os.environ.get("RD_AB_TIMING", "2")))
 for _ in range(10): bd.run()
 bd.results(); bd.timing()
 for _ in range(40): bd.run()

@@ -17,12 +17,14 @@ G[ea_stalls]="TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_R
 G[l2_hits]="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum"
 G[l2_busy]="TCC_BUSY_sum TCC_CYCLE_sum TCC_WRITEBACK_sum TCC_EA0_WRREQ_64B_sum"
 G[l1_latency]="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
-G[ta]="TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_LDS_WAVEFRONTS_sum"
+# (a TA_* group - TA_BUSY, TA_ADDR_STALLED_BY_TC_CYCLES, TA_DATA_STALLED_BY_TC_CYCLES, TA_FLAT_READ_LDS_WAVEFRONTS - made
+# rocprofv3 abort with signal 6 on this pool: not collected)
+G[utcl1]="TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_STALL_MULTI_MISS_sum"
 G[sq]="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"
 for V in $VARS; do
   IFS=: read NAME DBG OPT <<< "$V"
   export RD_K1_DEBUG=$DBG RD_K1_OPT=$OPT
-  for K in ea_latency ea_stalls l2_hits l2_busy l1_latency ta sq; do
+  for K in ea_latency ea_stalls l2_hits l2_busy l1_latency utcl1 sq; do
     D=$OUT/${NAME}_$K
     rm -rf $D
     timeout -k 10 180 rocprofv3 --pmc ${G[$K]} --output-format csv -d $D -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --sustain 0 --settle 0 > $D.log 2>&1
