@@ -375,10 +375,9 @@ static int batch_alloc(rd_batch *b) {
     if (b->ord_ok) {
         const size_t ns = (size_t)b->n_streams;
         HIPCHK(hipMalloc(&b->ord.smatch, ns * RD_BUCKET * sizeof(int32_t)));
-        HIPCHK(hipMalloc(&b->ord.tasks, ns * 2 * RD_BUCKET * RD_OTASK_BYTES));
-        HIPCHK(hipMalloc(&b->ord.skept, ns * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&b->ord.soff, ns * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&b->ord.wgtot, ((ns + 7) / 8) * sizeof(uint32_t)));
+        const size_t lists = (ns + RD_ORD_LIST_STREAMS - 1) / RD_ORD_LIST_STREAMS;
+        HIPCHK(hipMalloc(&b->ord.tasks, lists * RD_ORD_LIST_STREAMS * 2 * RD_BUCKET * RD_OTASK_BYTES));
+        HIPCHK(hipMalloc(&b->ord.wgtot, 2 * lists * sizeof(uint32_t)));
     }
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
@@ -400,7 +399,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
-        hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.skept); hipFree(b->ord.soff); hipFree(b->ord.wgtot);
+        hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.wgtot);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
@@ -772,11 +771,17 @@ extern "C" int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t
 // ------------------------------------------------------------------------------------------
 // One block in flight: pinned input, its device staging copy, pinned counters and mapped records.
 struct rd_slot {
-    uint8_t *h_in = nullptr;         // pinned: NS x 2B bytes (or B complex128)
+    uint8_t *h_in = nullptr;         // pinned + mapped: NS x 2B bytes (or B complex128)
+    uint8_t *d_in_map = nullptr;     // device address of h_in (the one-launch block reads its input from there)
     uint8_t *d_in = nullptr;         // device staging: the H2D copy lands here on the copy stream
     uint32_t *h_cnt = nullptr;       // pinned
     rd_packet *h_recs = nullptr;     // pinned + mapped, rec_cap entries: written by the slice kernel
     rd_packet *d_recs_map = nullptr; // device address of h_recs
+    // one-launch block (k_stream_block): per stream, matches found and the sequence number that says "done"
+    uint32_t *h_sb = nullptr;        // pinned + mapped: [NS] counts, [NS] flags
+    uint32_t *d_sb_map = nullptr;
+    uint32_t seq = 0;                // what the flags read once this slot's block is done
+    bool one = false;                // this slot's block went through k_stream_block
     hipEvent_t e_in = nullptr, e_done = nullptr;
 };
 
@@ -808,6 +813,9 @@ struct rd_demod {
     rd_order_scratch order;         // host ordering scratch
     uint32_t fix_cap = 0, match_cap = 0, rec_cap = 0;
     bool fast_ok = false;
+    bool one_ok = false;            // the configuration is one k_stream_block is built for (and RD_STREAM_IMPL != legacy)
+    uint32_t seq = 0;               // blocks sent through k_stream_block
+    std::vector<rd_packet> gather;  // records of a one-launch block, streams one after the other
 };
 
 extern "C" int rd_create_multi(const rd_config *cfg, int n_streams, rd_demod **out) {
@@ -856,8 +864,12 @@ static int demod_alloc(rd_demod *h) {
     const size_t in_bytes = std::max(16 * B, NS * 2 * B);
     for (int i = 0; i < 2; i++) {
         rd_slot &sl = h->slot[i];
-        HIPCHK(hipHostMalloc((void **)&sl.h_in, in_bytes, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&sl.h_in, in_bytes, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&sl.d_in_map, sl.h_in, 0));
         HIPCHK(hipMalloc(&sl.d_in, in_bytes));
+        HIPCHK(hipHostMalloc((void **)&sl.h_sb, 2 * NS * sizeof(uint32_t), hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&sl.d_sb_map, sl.h_sb, 0));
+        memset(sl.h_sb, 0, 2 * NS * sizeof(uint32_t));
         HIPCHK(hipHostMalloc((void **)&sl.h_cnt, RD_CNT_SLOTS * 4, hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&sl.h_recs, (size_t)h->rec_cap * sizeof(rd_packet), hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&sl.d_recs_map, sl.h_recs, 0));
@@ -867,6 +879,12 @@ static int demod_alloc(rd_demod *h) {
     HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
     HIPCHK(hipDeviceSynchronize());  // the memsets above ran on the null stream
+    {   // one launch per block where the kernel exists for the configuration; RD_STREAM_IMPL=legacy: the multi-launch form (A/B)
+        const char *e = getenv("RD_STREAM_IMPL");
+        const rd_devcfg &c = h->dc;
+        h->one_ok = !(e && e[0] == 'l') && h->fast_ok && c.S == 14 && c.P == 16 && c.K == 80 && c.pre_mask == 0x91D3ull &&
+                    c.L == 2 * c.B && c.B % 32 == 0 && c.B >= 2048 && c.B <= 16384;
+    }
     h->dev_ready = true;
     return RD_OK;
 }
@@ -883,7 +901,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         hipHostFree(h->h_tmp);
         for (int i = 0; i < 2; i++) {
             rd_slot &sl = h->slot[i];
-            hipHostFree(sl.h_in); hipFree(sl.d_in); hipHostFree(sl.h_cnt); hipHostFree(sl.h_recs);
+            hipHostFree(sl.h_in); hipFree(sl.d_in); hipHostFree(sl.h_cnt); hipHostFree(sl.h_recs); hipHostFree(sl.h_sb);
             if (sl.e_in) hipEventDestroy(sl.e_in);
             if (sl.e_done) hipEventDestroy(sl.e_done);
         }
@@ -904,7 +922,8 @@ extern "C" int rd_reset(rd_demod *h) {
     if (h->dev_ready) {
         // blocks still in flight are dropped: wait for them, then clear
         for (int i = 0; i < h->nflight; i++) {
-            int rc = wait_event(h->slot[(h->head + i) & 1].e_done);
+            rd_slot &sl = h->slot[(h->head + i) & 1];
+            int rc = sl.one ? wait_stream(h->st) : wait_event(sl.e_done);
             if (rc) return rc;
         }
         const size_t L = (size_t)h->dc.L;
@@ -974,6 +993,34 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
     hipStream_t st = h->st;
     const size_t nbytes = is_complex ? 2 * B * sizeof(double) : NS * 2 * B;
     memcpy(sl.h_in, samples, nbytes);
+    sl.one = false;
+    if (h->one_ok && !is_complex && !h->cplx_mode) {
+        // ONE launch: the kernel takes the block from the pinned buffer, rolls the ring, decides the bits exactly,
+        // searches, slices and leaves records, counts and a per-stream sequence number in mapped host memory
+        rd_sb_args a;
+        a.cfg = h->dc;
+        a.ring = h->d_ring;
+        a.ring_stride = h->ring_stride;
+        a.in = sl.d_in_map;
+        const int nw = h->cur_win ^ 1;
+        a.win_in = h->d_win[h->cur_win];
+        a.win_out = h->d_win[nw];
+        a.recs_host = sl.d_recs_map;
+        a.cnt_host = sl.d_sb_map;
+        a.flag_host = sl.d_sb_map + NS;
+        a.seq = ++h->seq;
+        a.seen_before = h->seen;
+        if (rd_launch_stream_block(a, h->NS, st)) {
+            HIPCHK(hipGetLastError());
+            h->cur_win = nw;
+            sl.seq = a.seq;
+            sl.one = true;
+            h->seen++;
+            h->nflight++;
+            return RD_OK;
+        }
+        --h->seq;
+    }
     HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, nbytes, hipMemcpyHostToDevice, h->st_copy));
     HIPCHK(hipEventRecord(sl.e_in, h->st_copy));
     HIPCHK(hipStreamWaitEvent(st, sl.e_in, 0));
@@ -1049,6 +1096,36 @@ static int demod_give(rd_demod *h, rd_packet *out, int cap, int *n) {
 static int demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {
     if (h->nflight == 0) return fail(RD_ERR_STATE, "no block in flight");
     rd_slot &sl = h->slot[h->head];
+    if (sl.one) {
+        // poll the streams' sequence numbers in pinned memory (an event query costs microseconds; a kernel that died
+        // would never write them, so the stream is asked now and then)
+        const size_t NS = (size_t)h->NS, per = (size_t)h->dc.B + 1;
+        volatile uint32_t *flag = sl.h_sb + NS;
+        for (size_t s = 0; s < NS; s++) {
+            for (uint32_t spins = 0; flag[s] != sl.seq; spins++) {
+                __builtin_ia32_pause();
+                if ((spins & 0xFFFF) == 0xFFFF) {
+                    const hipError_t e = hipStreamQuery(h->st);
+                    if (e != hipSuccess && e != hipErrorNotReady)
+                        return fail(RD_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+                    if (e == hipSuccess && flag[s] != sl.seq)
+                        return fail(RD_ERR_DEVICE, "the block's kernel finished without reporting stream %zu", s);
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        h->head ^= 1;
+        h->nflight--;
+        h->gather.clear();
+        for (size_t s = 0; s < NS; s++) {
+            const uint32_t c = std::min<uint32_t>(sl.h_sb[s], (uint32_t)per);
+            for (uint32_t i = 0; i < c; i++) h->gather.push_back(sl.h_recs[s * per + i]);
+        }
+        order_and_dedupe(h->gather.data(), h->gather.size(), h->dc.S, h->order);
+        h->last.clear();
+        for (uint32_t k : h->order.kept) h->last.push_back(h->gather[k]);
+        return demod_give(h, out, cap, n);
+    }
     int rc = wait_event(sl.e_done);
     if (rc) return rc;
     h->head ^= 1;

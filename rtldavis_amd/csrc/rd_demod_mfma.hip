@@ -59,6 +59,9 @@ typedef uint32_t rd_u2v __attribute__((ext_vector_type(2)));
 
 __device__ const rd_mf_taps g_mf_taps = rd_mf_make_taps();
 static const rd_mf_taps h_mf_taps = rd_mf_make_taps();
+__device__ const rd_mf_taps8 g_mf_taps8 = rd_mf_make_taps8();
+static const rd_mf_taps8 h_mf_taps8 = rd_mf_make_taps8();
+extern "C" void rd_debug_mfma_taps8(uint16_t *out) { memcpy(out, &h_mf_taps8, sizeof h_mf_taps8); }
 
 extern "C" void rd_debug_mfma_taps(uint16_t *out) { memcpy(out, &h_mf_taps, sizeof h_mf_taps); }
 
@@ -272,6 +275,152 @@ __device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (
     rd_mf_tail<B, DBG, WOFF>(g, xw, xr, st, dg, dleft);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// RD_OPT_B8: the 8-output formulation of rd_mfma.h - 16 MFMAs per tile instead of 24 (a matrix instruction in flight
+// slows the vector issue of the whole SIMD: with a third fewer of them the same vector work gets through sooner).
+// Lane (n, h), block b = 0..7: re / im of g[a0 + 8 b + 4 h + 1 + r'], r' = 0..3 - it decides the four signs of
+// t = base .. base + 3 (base = a0 + 8 b + 4 h): two from its own outputs, two with g[base - 1], g[base] of the lane
+// that precedes it in time ((n, 0, b) for h = 1, (n, 1, b - 1) for h = 0, (n - 1, 1, 7) for block 0 of half 0, the
+// previous tile's lane 63 for lane 0).  Those two are FINISHED one block later, under the next block's MFMAs: the
+// exchange's LDS round trip then costs nothing.  Block 0's are finished at the end of the tile.
+// Exchange buffers (per wave): Q (block 0) at 0, P1 (odd blocks) at 1024, P0 (even blocks >= 2) at 2048, the two
+// carry slots at 3072.
+struct rd_mf8_addr {
+    uint32_t xw;             // this lane's slot: + 0 / 1024 / 2048 for block 0 / odd / even
+    uint32_t xw7;            // block 7: the slot in P1, lane 63: the carry slot (toggles with the tile parity)
+    uint32_t rd1, rdE, rdO;  // predecessors of block 1 / the even blocks / the odd blocks >= 3
+    uint32_t rd0;            // block 0's, read at the end of the tile (lane 0: the carry slot, toggles)
+};
+struct rd_mf8_kept {  // what a block leaves for its deferred finish
+    float n2, n3;     // its two own numerators
+    float g0r, g0i;   // its first output (second boundary numerator)
+    float g1r, g1i, g2r, g2i;  // for the second-level guard (F over the group)
+    float nmin, tmax;
+};
+
+template <int B>
+__device__ __forceinline__ constexpr int rd_mf8_woff() { return B == 0 ? 0 : (B & 1) ? 1024 : 2048; }
+
+// finish block B >= 1: boundary numerators, guard band, the four signs into W (8 bits per block: four signs, then
+// four bits of no meaning that the last shift drags in - masked at the end of the tile)
+template <int B, int DBG>
+__device__ __forceinline__ void rd_mf8_finish(const rd_mf8_kept &k, rd_f4v &p, uint32_t &W, uint32_t &fb, bool &slow) {
+    rd_lds_wait(p);
+    float t0, t1;
+    const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, t0);
+    const float n1 = rd_mf_num(p.z, p.w, k.g0r, k.g0i, t1);
+    if (DBG == 0 || DBG == 3) {
+        const float nm = rd_mf_guard(rd_min3abs(k.nmin, n0, n1), rd_max3abs(k.tmax, t0, t1));
+        if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {  // rare; NaN counts as inside
+            slow = true;
+            float F = rd_max3abs(0.0f, p.x, p.y);
+            F = rd_max3abs(F, p.z, p.w);
+            F = rd_max3abs(F, k.g0r, k.g0i);
+            F = rd_max3abs(F, k.g1r, k.g1i);
+            F = rd_max3abs(F, k.g2r, k.g2i);
+            if (!(nm > rd_mf_c0(F))) fb |= 1u << (8 * (B & 3));
+        }
+    }
+    uint32_t w = rd_shift_in_sign(W, n0);
+    w = rd_shift_in_sign(w, n1);
+    w = rd_shift_in_sign(w, k.n2);
+    W = __builtin_amdgcn_alignbit(w, __builtin_bit_cast(uint32_t, k.n3), 27);  // (w << 5) | sign and four more bits
+}
+
+template <int B, int DBG>
+__device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v &dcC, const rd_u2v (&D)[9], rd_h8 &bfA,
+                                             const rd_mf8_addr &ad, rd_mf8_kept &k0, rd_mf8_kept &kp, rd_f4v &p, uint32_t &Wlo,
+                                             uint32_t &Whi, uint32_t &fblo, uint32_t &fbhi, bool &slow, float *dg, int dleft) {
+    const rd_h8 bfB = rd_mf_frag(D[B + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], bfA, dcC, 0, 0, 0);  // C: -D_hi in the hi rows
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], bfB, acc, 0, 0, 0);
+    // the previous block's finish runs under these two (block 0's waits for the end of the tile)
+    if (B >= 2) rd_mf8_finish<B - 1, DBG>(kp, p, B - 1 <= 3 ? Wlo : Whi, B - 1 <= 3 ? fblo : fbhi, slow);
+    __builtin_amdgcn_sched_barrier(0);
+    float g[8];  // g[2 r'], g[2 r' + 1] = re, im of output r'
+#pragma unroll
+    for (int i = 0; i < 8; i++) g[i] = __builtin_fmaf(acc[i], 2048.0f, acc[8 + i]);
+    if (DBG == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)  // the tile's last output (column 31, half 1, block 7, r' = 3) belongs to the next tile
+            if (8 * B + r < dleft) { dg[2 * (8 * B + r)] = g[2 * r]; dg[2 * (8 * B + r) + 1] = g[2 * r + 1]; }
+    }
+    {
+        const rd_f4v x = {g[4], g[5], g[6], g[7]};
+        if (B == 7) rd_lds_write16<0>(ad.xw7, x);
+        else rd_lds_write16<rd_mf8_woff<B>()>(ad.xw, x);
+    }
+    if (B >= 1) p = rd_lds_read16<0>(B == 1 ? ad.rd1 : (B & 1) ? ad.rdO : ad.rdE);  // consumed one block later
+    rd_mf8_kept &k = B == 0 ? k0 : kp;
+    float t2, t3;
+    k.n2 = rd_mf_num(g[0], g[1], g[2], g[3], t2);
+    k.n3 = rd_mf_num(g[2], g[3], g[4], g[5], t3);
+    k.nmin = rd_min3abs(3.0e38f, k.n2, k.n3);
+    k.tmax = rd_max3abs(0.0f, t2, t3);
+    k.g0r = g[0]; k.g0i = g[1];
+    k.g1r = g[2]; k.g1i = g[3]; k.g2r = g[4]; k.g2i = g[5];
+    bfA = bfB;
+}
+
+// One tile: `word` = word h of column n (final), `fbw` = its flag bytes (byte k != 0: group k inside the guard band).
+template <int DBG>
+__device__ __forceinline__ void rd_mf8_tile(const rd_h8 (&A)[2], const rd_f16v &dcC, const rd_u2v (&D)[9], const rd_mf8_addr &ad,
+                                            uint32_t &word, uint32_t &fbw, bool &slow, float *dg, int dleft) {
+    rd_h8 bfA = rd_mf_frag(D[0]);
+    rd_mf8_kept k0, kp;
+    rd_f4v p = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t Wlo = 0, Whi = 0, fblo = 0, fbhi = 0;
+    slow = false;
+    rd_mf8_block<0, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<1, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<2, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<3, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<4, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<5, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<6, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<7, DBG>(A, dcC, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    // block 0's predecessors (the previous column's block 7, this column's half 0, or the carry) together with block 7's
+    rd_f4v p0 = rd_lds_read16<0>(ad.rd0);
+    rd_mf8_finish<7, DBG>(kp, p, Whi, fbhi, slow);  // (its wait covers both reads)
+    {
+        rd_lds_wait(p0);
+        float t0, t1;
+        const float n0 = rd_mf_num(p0.x, p0.y, p0.z, p0.w, t0);
+        const float n1 = rd_mf_num(p0.z, p0.w, k0.g0r, k0.g0i, t1);
+        if (DBG == 0 || DBG == 3) {
+            // (block 0 keeps its outputs until here for the second-level test: listing its groups on the constant
+            // threshold alone made the fix-up list 76 % longer and k_fixup 8 us slower)
+            const float nm = rd_mf_guard(rd_min3abs(k0.nmin, n0, n1), rd_max3abs(k0.tmax, t0, t1));
+            if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {
+                slow = true;
+                float F = rd_max3abs(0.0f, p0.x, p0.y);
+                F = rd_max3abs(F, p0.z, p0.w);
+                F = rd_max3abs(F, k0.g0r, k0.g0i);
+                F = rd_max3abs(F, k0.g1r, k0.g1i);
+                F = rd_max3abs(F, k0.g2r, k0.g2i);
+                if (!(nm > rd_mf_c0(F))) fblo |= 1u;
+            }
+        }
+        uint32_t b0 = rd_shift_in_sign(0u, n0);
+        b0 = rd_shift_in_sign(b0, n1);
+        b0 = rd_shift_in_sign(b0, k0.n2);
+        b0 = __builtin_amdgcn_alignbit(b0, __builtin_bit_cast(uint32_t, k0.n3), 27);
+        Wlo = (b0 << 24) | Wlo;  // blocks 1-3 left 24 bits there
+    }
+    // a byte of W = [s0 s1 s2 s3 x x x x]: after the bit reversal block b's four signs are the low nibble of byte b & 3,
+    // sample order.  Word h of the column = half 0's nibbles | half 1's << 4, of blocks 0-3 (h = 0) or 4-7 (h = 1):
+    // the swap hands lane (n, 0) the other half's Vlo and lane (n, 1) the other half's Vhi.
+    const uint32_t Vlo = __builtin_bitreverse32(Wlo & 0xF0F0F0F0u), Vhi = __builtin_bitreverse32(Whi & 0xF0F0F0F0u);
+    const auto r = __builtin_amdgcn_permlane32_swap(Vlo, Vhi, false, false);
+    word = (r[1] << 4) | r[0];
+    fbw = 0;
+    if (slow && rd_mf_any((fblo | fbhi) != 0)) {
+        const auto f = __builtin_amdgcn_permlane32_swap(fblo, fbhi, false, false);
+        fbw = f[0] | f[1];
+    }
+}
+
 // cache policy of the tile loads (the builtin's aux operand): 0 default, 2 = nt.  The input is streamed
 // once and never re-read: nt loads-only 0.330 ms (6.7 TB/s) against 0.358, loads + stores 0.427 against 0.462,
 // whole kernel 0.496 against 0.509, and the search kernel behind it finds more of the bits in cache.
@@ -420,6 +569,7 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 #define RD_OPT_PIPE 1
 #define RD_OPT_HALO 2
 #define RD_OPT_STAMP 4
+#define RD_OPT_B8 8   // the 8-output formulation: 16 MFMAs per tile (rd_mf8_tile)
 #define RD_STAMP_WORDS 12
 template <int DBG, int NBUF, int OPT>
 __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
@@ -445,15 +595,29 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
 
     const int n = lane & 31, h = lane >> 5;
     // tap fragments: 6 x 4 registers for the whole kernel
+    constexpr bool B8 = (OPT & RD_OPT_B8) != 0;
     rd_h8 Ahi[3], Alo[3];
+    if (!B8) {
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        Ahi[d] = *(const rd_h8 *)g_mf_taps.v[0][d][lane];
-        Alo[d] = *(const rd_h8 *)g_mf_taps.v[1][d][lane];
+        for (int d = 0; d < 3; d++) {
+            Ahi[d] = *(const rd_h8 *)g_mf_taps.v[0][d][lane];
+            Alo[d] = *(const rd_h8 *)g_mf_taps.v[1][d][lane];
+        }
+        // a use in front of the loop: the wait for these six loads must not end up inside it, where it would
+        // be a vmcnt(0) that also drains the prefetched tiles in every iteration
+        asm volatile("" : "+v"(Ahi[0]), "+v"(Ahi[1]), "+v"(Ahi[2]), "+v"(Alo[0]), "+v"(Alo[1]), "+v"(Alo[2]));
     }
-    // a use in front of the loop: the wait for these six loads must not end up inside it, where it would
-    // be a vmcnt(0) that also drains the prefetched tiles in every iteration
-    asm volatile("" : "+v"(Ahi[0]), "+v"(Ahi[1]), "+v"(Ahi[2]), "+v"(Alo[0]), "+v"(Alo[1]), "+v"(Alo[2]));
+    rd_h8 A8[2];
+    rd_f16v dcC;  // the C operand of a block's first MFMA: -D_hi in the hi-digit rows, 0 in the lo-digit rows
+    if (B8) {
+        A8[0] = *(const rd_h8 *)g_mf_taps8.v[0][lane];
+        A8[1] = *(const rd_h8 *)g_mf_taps8.v[1][lane];
+        const float dchi = -(float)RD_MF_DHI / 16777216.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) dcC[i] = i < 8 ? dchi : 0.0f;
+        // opaque: sixteen registers for the whole kernel, not sixteen v_mov in front of every block
+        asm volatile("" : "+v"(A8[0]), "+v"(A8[1]), "+v"(dcC));
+    }
     // window addresses in the image (buffer 0; buffer 1 is RD_MF_IMG_PAD further)
     const uint32_t img_addr = rd_lds_addr(img0);
     const uint32_t own = 16 + RD_MF_GROUP_BYTES * (n >> 3) + 16 * (n & 7) + 8 * h;
@@ -473,6 +637,13 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     const uint32_t xr3 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 2048 + 16 * (lane + 32));   // X3[l-32] | X2[l+32]
     uint32_t xr0 = xb_addr + (h ? 16 * (lane - 32) : lane ? 1024 + 16 * (lane + 31) : 3072 + 16);  // X0[l-32] | X3[l+31]
     const uint32_t rtoggle = lane == 0 ? 16u : 0u, wtoggle = lane == 63 ? 16u : 0u;
+    rd_mf8_addr ad8;
+    ad8.xw = xw;
+    ad8.xw7 = xb_addr + (lane == 63 ? 3072 : 1024 + 16 * lane);
+    ad8.rd1 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 16 * (lane + 32));
+    ad8.rdE = xb_addr + (h ? 2048 + 16 * (lane - 32) : 1024 + 16 * (lane + 32));
+    ad8.rdO = xb_addr + (h ? 1024 + 16 * (lane - 32) : 2048 + 16 * (lane + 32));
+    ad8.rd0 = xb_addr + (h ? 16 * (lane - 32) : lane ? 1024 + 16 * (lane + 31) : 3072 + 16);
     if (lane < 8) ((uint32_t *)(xb + 3072))[lane] = 0;  // carry slots: finite values from the start
     // -D_hi * 2^-24 (the -127.4 offset): read into all sixteen positions of the hi accumulator in front of
     // every block's MFMAs - from LDS rather than from a 16-register tuple held for the whole kernel
@@ -583,9 +754,16 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
 
         uint32_t word = 0, fbytes = 0;
         bool slow_taken = false;
+        uint32_t fbw8 = 0;  // B8: the word's flag bytes, already gathered
         if (DBG == 2 || DBG == 6) {
 #pragma unroll
             for (int j = 0; j < 9; j++) word ^= D[j].x ^ D[j].y;
+        } else if (B8) {
+            float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 4 * h + 1) * 2 : nullptr;
+            const int dleft = RD_TILE_SAMPLES - (64 * n + 4 * h + 1);
+            rd_mf8_tile<DBG>(A8, dcC, D, ad8, word, fbw8, slow_taken, dg, dleft);
+            ad8.rd0 ^= rtoggle;
+            ad8.xw7 ^= wtoggle;
         } else {
             rd_h8 bf[3];
             rd_mf_state stt;
@@ -655,7 +833,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         // The lane holds bytes (groups) 2b + h of its column's two words: gather word h of the column
         // (lanes n and n + 32 exchange halves), the flags likewise.
         uint32_t gmask = 0;
-        {
+        if (!B8 || DBG == 2 || DBG == 6) {
             const auto w2 = __builtin_amdgcn_permlane32_swap(word, word, false, false);  // [0]: half 0's, [1]: half 1's
             word = __builtin_amdgcn_perm(w2[1], w2[0], psel);
         }
@@ -663,8 +841,10 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         const uint32_t run = ti * 64 + 2 * n + h;  // word index in the stream
         const uint32_t t0 = run * RD_RUN;
         // (fbytes is only ever set inside the wave-uniform second-level branches: no ballot in the common case)
-        const bool any_flag = slow_taken && rd_mf_any(fbytes != 0);
-        if (any_flag) {  // wave-uniform, rare
+        const bool any_flag = slow_taken && rd_mf_any(B8 ? fbw8 != 0 : fbytes != 0);
+        if (B8) {
+            if (any_flag) gmask = ((fbw8 * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
+        } else if (any_flag) {  // wave-uniform, rare
             const auto f2 = __builtin_amdgcn_permlane32_swap(fbytes, fbytes, false, false);
             const uint32_t fb = __builtin_amdgcn_perm(f2[1], f2[0], psel);
             gmask = ((fb * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
@@ -741,7 +921,7 @@ static int rd_mf_env(const char *name, int dflt) {
 
 // What the shipped kernel is built with (-DRD_MF_PRODUCT_OPT=n overrides; the diagnostic library selects at run time)
 #ifndef RD_MF_PRODUCT_OPT
-#define RD_MF_PRODUCT_OPT RD_OPT_HALO
+#define RD_MF_PRODUCT_OPT (RD_OPT_HALO | RD_OPT_B8)
 #endif
 
 // Launch parameters read once per process.  A function-local static: initialised exactly once, also when several
@@ -860,14 +1040,20 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     a.fix_list = fix_list; a.fix_cap = fix_cap; a.counters = counters;
     a.st = st; a.ev_start = ev_start; a.ev_stop = ev_stop; a.dbg_g = dbg_g;
     if (dbg_g) {  // the test hook: raw filter outputs as well
+#ifdef RD_DIAG
+        if ((rd_mf_get_params().opt & RD_OPT_B8) != (RD_MF_PRODUCT_OPT & RD_OPT_B8)) {
+            rd_mf_launch_variant<3, 1, (RD_MF_PRODUCT_OPT ^ RD_OPT_B8)>(a);
+            return;
+        }
+#endif
         rd_mf_launch_variant<3, 1, RD_MF_PRODUCT_OPT>(a);
         return;
     }
 #ifdef RD_DIAG
     const rd_mf_params &P = rd_mf_get_params();
-    const int key = P.dbg * 100 + P.nbuf * 10 + P.opt;  // (opt < 8)
+    const int key = P.dbg * 1000 + P.nbuf * 100 + P.opt;  // (opt < 100)
     switch (key) {
-#define RD_V(D, NB, O) case (D) * 100 + (NB) * 10 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
+#define RD_V(D, NB, O) case (D) * 1000 + (NB) * 100 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
         RD_V(0, 1, 0) RD_V(0, 1, 1) RD_V(0, 1, 2) RD_V(0, 1, 3) RD_V(0, 1, 4) RD_V(0, 1, 5) RD_V(0, 1, 6) RD_V(0, 1, 7)
         RD_V(1, 1, 0) RD_V(1, 1, 1)
         RD_V(2, 1, 0) RD_V(2, 1, 2) RD_V(2, 1, 4) RD_V(2, 1, 6)
@@ -875,6 +1061,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
         RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
         RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
         RD_V(10, 1, 0) RD_V(10, 1, 4) RD_V(11, 1, 0) RD_V(11, 1, 4)
+        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10)
         RD_V(0, 2, 0)
 #undef RD_V
         default:

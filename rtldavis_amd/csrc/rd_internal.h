@@ -75,12 +75,13 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
 // RSSI / SNR, records written in the reference's order.  RD_BUCKET matches per stream at most.
 #define RD_BUCKET 32
 #define RD_OTASK_BYTES 32
+#define RD_ORD_LIST_STREAMS 8    /* streams whose surviving tasks form one dense list (one workgroup of k_classify_ord) */
+#define RD_ORD_SUPER 4           /* consecutive lists that k_rssi_ord deals out to its waves as one */
 struct rd_ord_bufs {
     int32_t *smatch = nullptr;   // [n_streams][RD_BUCKET] positions
     uint32_t *scount = nullptr;  // [n_streams] matches found (lives behind the counter set of the run: cleared with it)
-    void *tasks = nullptr;       // [n_streams][2 RD_BUCKET] entries of RD_OTASK_BYTES
-    uint32_t *skept = nullptr, *soff = nullptr;  // [n_streams] surviving tasks, their offset inside the workgroup of 8 streams
-    uint32_t *wgtot = nullptr;   // [(n_streams + 7) / 8] surviving tasks per workgroup
+    void *tasks = nullptr;       // [lists][RD_ORD_LIST_STREAMS * 2 RD_BUCKET] entries of RD_OTASK_BYTES: one dense list per 8 streams
+    uint32_t *wgtot = nullptr;   // [2][lists] surviving tasks per list, matches per list; lists = ceil(n_streams / RD_ORD_LIST_STREAMS)
 };
 int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
                            const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
@@ -113,6 +114,25 @@ void rd_launch_filtered(const rd_layout &lay, int stream, long t0, long n, doubl
 void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_win_bits, const uint32_t *block,
                              long n_block_bits, int n_streams, size_t win_stride, size_t block_stride,
                              hipStream_t st);
+
+// The streaming handle's one-launch block (k_stream_block, rd_kernels.hip): everything of one demodulate() call - ring
+// roll, exact bits, window, search, slice + RSSI, results into mapped host memory - for NS streams in lock step.
+#define RD_SB_THREADS 1024
+struct rd_sb_args {
+    rd_devcfg cfg;
+    uint8_t *ring;            // the streams' raw rings: [hdr 32 B][previous block][newest block], ring_stride apart
+    size_t ring_stride;
+    const uint8_t *in;        // device address of the pinned input: NS x 2B bytes
+    const uint32_t *win_in;   // quantized window before this block (2B bits per stream)
+    uint32_t *win_out;        // ... and after it
+    rd_packet *recs_host;     // mapped host memory: B + 1 records per stream (record i of a stream = its match i)
+    uint32_t *cnt_host;       // mapped: matches per stream
+    uint32_t *flag_host;      // mapped: seq per stream, stored last
+    uint32_t seq;
+    long seen_before;         // blocks since reset
+};
+// 1 when the kernel was launched, 0 when the configuration is not one it is built for
+int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st);
 
 // complex128 input path (py:144-150): raw ring of interleaved doubles
 struct rd_cplx_layout {

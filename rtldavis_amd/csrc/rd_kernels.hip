@@ -513,20 +513,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
             for (int o = 0; o < RD_SEARCH_OUT; o++) {
                 uint32_t mm = m[o];
                 uint64_t any = __ballot(mm != 0);
-                while (BKT && any) {  // (s is wave-uniform: one atomic per round)
-                    const uint32_t nf = (uint32_t)__popcll(any);
-                    uint32_t slot0 = 0;
-                    if (lane == 0) slot0 = atomicAdd(&scount[s], nf);
-                    slot0 = __builtin_amdgcn_readfirstlane(slot0);
-                    if (mm) {
-                        const int bpos = __builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const uint32_t slot = slot0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32),
-                                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0));
-                        if (slot < RD_BUCKET) smatch[(size_t)s * RD_BUCKET + slot] = (int32_t)(p0 + 32 * o + bpos);
-                    }
-                    any = __ballot(mm != 0);
-                }
+                if (BKT) any = 0;  // (handled for the four words together behind this loop)
                 while (any) {  // each round, every lane with matches left contributes its lowest one
                     const uint32_t nf = (uint32_t)__popcll(any);
                     if (npend + nf > RD_MATCH_PEND) {
@@ -544,6 +531,33 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
                     }
                     npend += nf;
                     any = __ballot(mm != 0);
+                }
+            }
+            if (BKT) {
+                // per-stream buckets: ONE returning atomic per wave-group that found anything (3 in 10 do), for all
+                // four output words of all lanes - a lane's slots follow those of the lanes below it
+                const uint32_t mine = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+                if (__ballot(mine != 0)) {  // wave-uniform
+                    uint32_t incl = mine;
+#pragma unroll
+                    for (int sh = 1; sh < 64; sh <<= 1) {
+                        const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
+                        if (lane >= sh) incl += up;
+                    }
+                    const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+                    uint32_t slot0 = 0;
+                    if (lane == 0) slot0 = atomicAdd(&scount[s], tot);
+                    uint32_t slot = __builtin_amdgcn_readfirstlane(slot0) + incl - mine;
+#pragma unroll
+                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                        uint32_t mm = m[o];
+                        while (mm) {  // (lane-divergent, a few iterations at most)
+                            const int bpos = __builtin_ctz(mm);
+                            mm &= mm - 1;
+                            if (slot < RD_BUCKET) smatch[(size_t)s * RD_BUCKET + slot] = (int32_t)(p0 + 32 * o + bpos);
+                            slot++;
+                        }
+                    }
                 }
             }
         }
@@ -1169,31 +1183,38 @@ __global__ __launch_bounds__(256) void k_rssi_u8(rd_layout lay, rd_devcfg cfg, c
 //                        every task of the stream sits in the same half-wave - the exact dedupe and the rank of each
 //                        surviving task by two short loops of lane broadcasts; per-stream counts, their prefix inside
 //                        the workgroup and the workgroup's total
-//   k_rssi_ord         : one wave per stream: adds the totals of the workgroups in front of its own (at most
-//                        n_streams / 8 words), evaluates the RSSI / SNR windows of its tasks on the matrix pipe as
-//                        k_rssi_u8 does and writes each whole record at its final position
+//   k_rssi_ord         : eight waves per workgroup list of k_classify_ord: adds the totals of the lists in front (at
+//                        most n_streams / 8 words), evaluates the RSSI / SNR windows of its tasks on the matrix pipe
+//                        as k_rssi_u8 does and writes each whole record at its final position
 // A stream with more than RD_BUCKET matches (or more records than the list holds) raises RD_CNT_OVF and the host
 // falls back to the unordered kernels above for that input.
 // ------------------------------------------------------------------------------------------
 struct rd_otask {   // 32 bytes
     int32_t call, q;
     uint32_t d[3];  // the packet's bytes (K_ = 80: ten of them)
-    uint32_t pad[3];
+    int32_t stream;
+    uint32_t pad[2];
 };
+#define RD_ORD_WG_STREAMS RD_ORD_LIST_STREAMS                 /* streams per workgroup of k_classify_ord */
+#define RD_ORD_WG_TASKS (RD_ORD_WG_STREAMS * 2 * RD_BUCKET)   /* task entries per workgroup list */
 
 template <int S_, int K_>
-__global__ __launch_bounds__(256) void k_classify_ord(const uint32_t *bits, size_t bits_stride, int nwords, rd_devcfg cfg,
+__global__ __launch_bounds__(32 * RD_ORD_WG_STREAMS) void k_classify_ord(const uint32_t *bits, size_t bits_stride, int nwords, rd_devcfg cfg,
                                                       const int32_t *smatch, const uint32_t *scount, int n_streams,
-                                                      uint32_t bucket_limit, int n_calls, rd_otask *tasks, uint32_t *skept,
-                                                      uint32_t *soff, uint32_t *wgtot, uint32_t rec_cap, uint32_t *counters) {
+                                                      uint32_t bucket_limit, int n_calls, rd_otask *tasks,
+                                                      uint32_t *wgtot, uint32_t *counters) {
     constexpr int NBITS = (K_ - 1) * S_ + 1;          // bits pos .. of the packet
     constexpr int NU = (NBITS + 31) / 32;
     constexpr int NW = NU + 1;
     constexpr int NBYTES = (K_ + 7) / 8;
     static_assert(K_ % 8 == 0 && NBYTES <= 12, "at most 12 packet bytes in a task entry");
-    __shared__ uint32_t s_k[8], s_m[8];
+    static_assert(NW <= 36, "the load fence below names 36 words");
+    __shared__ uint32_t s_k[RD_ORD_WG_STREAMS], s_m[RD_ORD_WG_STREAMS];
+    // per stream (half-wave) and match: {flags, call b0, key 0, key 1, bytes[3], -}: read back with the same address in
+    // all 32 lanes (a broadcast), instead of six ds_bpermute per step of the loops below
+    __shared__ __attribute__((aligned(16))) uint32_t s_t[RD_ORD_WG_STREAMS][RD_BUCKET][8];
     const int lane = threadIdx.x & 63, sub = lane & 31, grp = threadIdx.x >> 5;
-    const int stream = blockIdx.x * 8 + grp;
+    const int stream = blockIdx.x * RD_ORD_WG_STREAMS + grp;
     uint32_t count = stream < n_streams ? scount[stream] : 0u;
     const uint32_t nmatch = count;
     const bool ovf = count > bucket_limit;
@@ -1201,6 +1222,22 @@ __global__ __launch_bounds__(256) void k_classify_ord(const uint32_t *bits, size
     const bool live = (uint32_t)sub < count;
     int pos = 0;
     if (live) pos = smatch[(size_t)stream * RD_BUCKET + sub];
+    // the words that hold the packet's symbols: ALL loads issued before the first use (the fence below) - taken a few
+    // at a time they cost this kernel a memory latency per batch
+    const uint32_t *w = bits + (size_t)(stream < n_streams ? stream : 0) * bits_stride;
+    const int wi0 = pos >> 5;
+    const uint32_t sh = (uint32_t)(pos & 31);
+    uint32_t W[36];
+#pragma unroll
+    for (int j = 0; j < 36; j++) {
+        const int wi = wi0 + j;
+        W[j] = (j < NW && live && wi >= 0 && wi < nwords) ? w[wi] : 0u;
+    }
+    asm volatile("" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(W[4]), "+v"(W[5]), "+v"(W[6]), "+v"(W[7]), "+v"(W[8]),
+                      "+v"(W[9]), "+v"(W[10]), "+v"(W[11]), "+v"(W[12]), "+v"(W[13]), "+v"(W[14]), "+v"(W[15]), "+v"(W[16]), "+v"(W[17]));
+    asm volatile("" : "+v"(W[18]), "+v"(W[19]), "+v"(W[20]), "+v"(W[21]), "+v"(W[22]), "+v"(W[23]), "+v"(W[24]), "+v"(W[25]),
+                      "+v"(W[26]), "+v"(W[27]), "+v"(W[28]), "+v"(W[29]), "+v"(W[30]), "+v"(W[31]), "+v"(W[32]), "+v"(W[33]),
+                      "+v"(W[34]), "+v"(W[35]));
     // calls that report this position (py:194, q <= B), as in k_classify
     const uint32_t pl = (uint32_t)(pos + cfg.L), bq = pl / (uint32_t)cfg.B, br = pl - bq * (uint32_t)cfg.B;
     const int b0 = (int)bq - 1;
@@ -1209,15 +1246,6 @@ __global__ __launch_bounds__(256) void k_classify_ord(const uint32_t *bits, size
     const int b1 = b0 - 1, q1 = q0 + cfg.B;
     const bool ok1 = live && br == 0 && b1 >= 0 && b1 < n_calls;
     // the packet's bytes: byte bi = symbols 8 bi .. 8 bi + 7, first symbol = MSB (py:197-200)
-    const uint32_t *w = bits + (size_t)(stream < n_streams ? stream : 0) * bits_stride;
-    const int wi0 = pos >> 5;
-    const uint32_t sh = (uint32_t)(pos & 31);
-    uint32_t W[NW];
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-        const int wi = wi0 + j;
-        W[j] = (live && wi >= 0 && wi < nwords) ? w[wi] : 0u;
-    }
     uint32_t u[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) u[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], sh);
@@ -1231,118 +1259,161 @@ __global__ __launch_bounds__(256) void k_classify_ord(const uint32_t *bits, size
     // keys: (call, phase, q), the order of py:171-188 inside a call; task 0 = (b0, q0), task 1 = (b0 - 1, q0 + B)
     const uint32_t ph0 = (uint32_t)q0 % (uint32_t)S_, ph1 = (uint32_t)q1 % (uint32_t)S_;
     const uint32_t k0 = (ph0 << 24) | (uint32_t)q0, k1 = (ph1 << 24) | (uint32_t)q1;  // q <= B < 2^24 (checked by the host)
+    {
+        uint4 *e = (uint4 *)s_t[grp][sub];
+        e[0] = uint4{(ok0 ? 1u : 0u) | (ok1 ? 2u : 0u), (uint32_t)b0, k0, k1};
+        e[1] = uint4{dw[0], dw[1], dw[2], 0u};
+    }
     uint32_t maxc = count;
     maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, 32, 64));
     maxc = __builtin_amdgcn_readfirstlane(maxc);
-    const int src0 = lane & 32;
+    // (a half-wave reads what the same wave wrote: LDS operations of a wave complete in order, no barrier needed)
     // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205)
     bool dup0 = false, dup1 = false;
     for (uint32_t j = 0; j < maxc; j++) {
-        const int src = src0 + (int)j;
-        const uint32_t oflags = (uint32_t)__shfl((int)((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)), src, 64);
-        const int ob0 = __shfl(b0, src, 64);
-        const uint32_t ok0_ = (uint32_t)__shfl((int)k0, src, 64), ok1_ = (uint32_t)__shfl((int)k1, src, 64);
-        const bool same = (uint32_t)__shfl((int)dw[0], src, 64) == dw[0] && (uint32_t)__shfl((int)dw[1], src, 64) == dw[1] &&
-                          (uint32_t)__shfl((int)dw[2], src, 64) == dw[2];
-        if (same) {
-            if ((oflags & 1u) && ob0 == b0 && ok0_ < k0) dup0 = true;
-            if ((oflags & 2u) && ob0 - 1 == b0 && ok1_ < k0) dup0 = true;
-            if ((oflags & 1u) && ob0 == b1 && ok0_ < k1) dup1 = true;
-            if ((oflags & 2u) && ob0 - 1 == b1 && ok1_ < k1) dup1 = true;
+        const uint4 a = *(const uint4 *)s_t[grp][j], d = *(const uint4 *)(s_t[grp][j] + 4);
+        const int ob0 = (int)a.y;
+        if (d.x == dw[0] && d.y == dw[1] && d.z == dw[2]) {
+            if ((a.x & 1u) && ob0 == b0 && a.z < k0) dup0 = true;
+            if ((a.x & 2u) && ob0 - 1 == b0 && a.w < k0) dup0 = true;
+            if ((a.x & 1u) && ob0 == b1 && a.z < k1) dup1 = true;
+            if ((a.x & 2u) && ob0 - 1 == b1 && a.w < k1) dup1 = true;
         }
     }
     const bool kept0 = ok0 && !dup0, kept1 = ok1 && !dup1;
+    s_t[grp][sub][0] = (kept0 ? 1u : 0u) | (kept1 ? 2u : 0u);
     // pass 2: rank among the surviving tasks of the stream
     uint32_t r0 = 0, r1 = 0;
     for (uint32_t j = 0; j < maxc; j++) {
-        const int src = src0 + (int)j;
-        const uint32_t oflags = (uint32_t)__shfl((int)((kept0 ? 1u : 0u) | (kept1 ? 2u : 0u)), src, 64);
-        const int ob0 = __shfl(b0, src, 64);
-        const uint32_t ok0_ = (uint32_t)__shfl((int)k0, src, 64), ok1_ = (uint32_t)__shfl((int)k1, src, 64);
+        const uint4 a = *(const uint4 *)s_t[grp][j];
+        const int ob0 = (int)a.y;
         auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
-        if (oflags & 1u) { r0 += before(ob0, ok0_, b0, k0) ? 1u : 0u; r1 += before(ob0, ok0_, b1, k1) ? 1u : 0u; }
-        if (oflags & 2u) { r0 += before(ob0 - 1, ok1_, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, ok1_, b1, k1) ? 1u : 0u; }
+        if (a.x & 1u) { r0 += before(ob0, a.z, b0, k0) ? 1u : 0u; r1 += before(ob0, a.z, b1, k1) ? 1u : 0u; }
+        if (a.x & 2u) { r0 += before(ob0 - 1, a.w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, a.w, b1, k1) ? 1u : 0u; }
     }
+    const int src0 = lane & 32;
     const uint64_t m0 = __ballot(kept0), m1 = __ballot(kept1);
     const uint32_t kept = (uint32_t)__popc((uint32_t)(m0 >> src0)) + (uint32_t)__popc((uint32_t)(m1 >> src0));
-    rd_otask *tk = tasks + (size_t)(stream < n_streams ? stream : 0) * (2 * RD_BUCKET);
-    if (kept0) { rd_otask t = {b0, q0, {dw[0], dw[1], dw[2]}, {0, 0, 0}}; tk[r0] = t; }
-    if (kept1) { rd_otask t = {b1, q1, {dw[0], dw[1], dw[2]}, {0, 0, 0}}; tk[r1] = t; }
     if (sub == 0) { s_k[grp] = kept; s_m[grp] = nmatch; }
     if (ovf && sub == 0) atomicOr(&counters[RD_CNT_OVF], 1u);
     __syncthreads();
-    if (sub == 0 && stream < n_streams) {
-        uint32_t off = 0;
-        for (int g = 0; g < grp; g++) off += s_k[g];
-        skept[stream] = kept;
-        soff[stream] = off;
-    }
+    // the workgroup's list: its streams' tasks one stream after the other, each stream's in rank order
+    uint32_t off = 0;
+#pragma unroll
+    for (int g = 0; g < RD_ORD_WG_STREAMS; g++) off += g < grp ? s_k[g] : 0u;
+    rd_otask *tk = tasks + (size_t)blockIdx.x * RD_ORD_WG_TASKS + off;
+    if (kept0) { rd_otask t = {b0, q0, {dw[0], dw[1], dw[2]}, stream, {0, 0}}; tk[r0] = t; }
+    if (kept1) { rd_otask t = {b1, q1, {dw[0], dw[1], dw[2]}, stream, {0, 0}}; tk[r1] = t; }
     if (threadIdx.x == 0) {
+        // the list's totals: plain stores, summed by k_rssi_ord - one atomic per workgroup on the shared counter line
+        // cost 12 us here (a counter word takes ~90 atomics per microsecond, and there are n_streams / 8 workgroups)
         uint32_t tot = 0, mt = 0;
-        for (int g = 0; g < 8; g++) { tot += s_k[g]; mt += s_m[g]; }
+        for (int g = 0; g < RD_ORD_WG_STREAMS; g++) { tot += s_k[g]; mt += s_m[g]; }
         wgtot[blockIdx.x] = tot;
-        if (tot) {
-            const uint32_t before = atomicAdd(&counters[RD_CNT_TASKS], tot);
-            if (before + tot > rec_cap) atomicOr(&counters[RD_CNT_OVF], 2u);
-        }
-        if (mt) atomicAdd(&counters[RD_CNT_MATCH], mt);
+        wgtot[gridDim.x + blockIdx.x] = mt;
     }
 }
 
-// One wave per stream; the tasks of a stream are consecutive entries, so the next task's window bytes are fetched
-// while the current one runs on the matrix pipe (as in k_rssi_u8).
-__global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, const rd_otask *tasks, const uint32_t *skept,
-                                                  const uint32_t *soff, const uint32_t *wgtot, int n_streams, int nbytes,
-                                                  rd_packet *recs, uint32_t rec_cap, const uint32_t *counters) {
+// k_rssi_ord deals RD_ORD_SUPER consecutive lists of k_classify_ord (32 streams) out to RD_ORD_RSSI_WAVES waves as
+// ONE list: wave w takes entries w, w + 32, ... - the same ~6 packets per wave as k_rssi_u8 and nearly as evenly
+// (8-stream lists dealt out one by one left the slowest wave with half as many again).  An entry's final position: the
+// totals of the lists in front (summed here: at most n_streams / 8 words, one round of loads) plus its index.
+#define RD_ORD_RSSI_WAVES (RD_ORD_SUPER * RD_ORD_LIST_STREAMS)
+__global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, const rd_otask *tasks, const uint32_t *wgtot,
+                                                  int n_lists, int nbytes, rd_packet *recs, uint32_t rec_cap,
+                                                  uint32_t *counters) {
     const int lane = threadIdx.x & 63;
-    const int stream = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (stream >= n_streams) return;
-    if (counters[RD_CNT_OVF]) return;  // the host discards this run's records
-    const uint32_t n = skept[stream];
-    if (n == 0) return;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int sup = gw / RD_ORD_RSSI_WAVES, wv = gw % RD_ORD_RSSI_WAVES;
+    const int list0 = sup * RD_ORD_SUPER;
+    if (list0 >= n_lists) return;
+    // records in front of this super-list, its lists' lengths, the overflow flag: independent loads, ONE wait (eight
+    // predicated loads per lane cover 512 lists; a loop with a run-time trip count waits for every load in turn)
+    uint32_t part = 0;
+    for (int base = 0; base < list0; base += 512) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = base + lane + 64 * k;
+            v[k] = i < list0 ? wgtot[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) part += v[k];
+    }
+    uint32_t nl[RD_ORD_SUPER];
+#pragma unroll
+    for (int k = 0; k < RD_ORD_SUPER; k++) nl[k] = list0 + k < n_lists ? wgtot[list0 + k] : 0u;
+    const uint32_t ovf = counters[RD_CNT_OVF];
+    // the last super-list's first wave also leaves the run's totals for the host (records, matches)
+    const bool totals = list0 + RD_ORD_SUPER >= n_lists && wv == 0;
+    uint32_t mt = 0;
+    if (totals)
+        for (int i = lane; i < n_lists; i += 64) mt += wgtot[n_lists + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(part);
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < RD_ORD_SUPER; k++) n += nl[k];
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (totals) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mt += (uint32_t)__shfl_xor((int)mt, o, 64);
+        if (lane == 0) {
+            counters[RD_CNT_TASKS] = first + n;
+            counters[RD_CNT_MATCH] = mt;
+            if (first + n > rec_cap) counters[RD_CNT_OVF] = ovf | 2u;
+        }
+    }
+    if (ovf || (uint32_t)wv >= n) return;  // (overflow: the host discards this run's records)
     rd_k_h8 Ahi[3], Alo[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
         Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
     }
-    // records in front of this stream: the workgroups of k_classify_ord before its own, then its place inside
-    uint32_t part = 0;
-    const int wg = stream >> 3;
-    for (int i = lane; i < wg; i += 64) part += wgtot[i];
+    // entry e of the super-list = entry e - (lengths of the lists before it) of one of its lists
+    auto entry = [&](uint32_t e) -> const rd_otask * {
+        uint32_t k = 0, pre = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(part) + soff[stream];
-    rd_stream_view v;
-    v.base = lay.iq + (size_t)stream * lay.stream_stride;
-    v.valid_from = lay.valid_from;
-    v.n = lay.n_samples;
-    const rd_otask *tk = tasks + (size_t)stream * (2 * RD_BUCKET);
-    rd_otask t_cur = tk[0], t_nxt = n > 1 ? tk[1] : tk[0];
-    auto job_of = [&](const rd_otask &t) {
-        return rd_rssi_prepare(v, __builtin_amdgcn_readfirstlane(t.call) * cfg.B, cfg, __builtin_amdgcn_readfirstlane(t.q), lane);
+        for (int j = 0; j < RD_ORD_SUPER - 1; j++)
+            if (k == (uint32_t)j && e >= pre + nl[j]) { pre += nl[j]; k = j + 1; }
+        return tasks + (size_t)(list0 + k) * RD_ORD_WG_TASKS + (e - pre);
     };
+    auto view = [&](int stream) {
+        rd_stream_view v;
+        v.base = lay.iq + (size_t)stream * lay.stream_stride;
+        v.valid_from = lay.valid_from;
+        v.n = lay.n_samples;
+        return v;
+    };
+    auto job_of = [&](const rd_otask &t) {
+        return rd_rssi_prepare(view(__builtin_amdgcn_readfirstlane(t.stream)), __builtin_amdgcn_readfirstlane(t.call) * cfg.B, cfg,
+                               __builtin_amdgcn_readfirstlane(t.q), lane);
+    };
+    rd_otask t_cur = *entry((uint32_t)wv), t_nxt = *entry((uint32_t)wv + RD_ORD_RSSI_WAVES < n ? wv + RD_ORD_RSSI_WAVES : wv);
     rd_rssi_job j_cur = job_of(t_cur);
     rd_rssi_data d_cur = {};
     if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
-    for (uint32_t r = 0; r < n; r++) {
+    for (uint32_t r = (uint32_t)wv; r < n; r += RD_ORD_RSSI_WAVES) {
         const rd_otask t_now = t_cur;
         const rd_rssi_job j_now = j_cur;
         const rd_rssi_data d_now = d_cur;
-        if (r + 1 < n) {
+        if (r + RD_ORD_RSSI_WAVES < n) {
             j_cur = job_of(t_nxt);
             if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
         }
         t_cur = t_nxt;
-        if (r + 2 < n) t_nxt = tk[r + 2];
+        if (r + 2 * RD_ORD_RSSI_WAVES < n) t_nxt = *entry(r + 2 * RD_ORD_RSSI_WAVES);
         double rssi = 0.0, snr = 0.0;
-        const int call = __builtin_amdgcn_readfirstlane(t_now.call), q = __builtin_amdgcn_readfirstlane(t_now.q);
+        const int stream = __builtin_amdgcn_readfirstlane(t_now.stream), call = __builtin_amdgcn_readfirstlane(t_now.call),
+                  q = __builtin_amdgcn_readfirstlane(t_now.q);
         if (j_now.ok) {
             float noise, sig;
             rd_rssi_block(j_now, d_now, Ahi, Alo, lane, noise, sig);
             rd_rssi_finish(noise, sig, j_now.ns, j_now.pe, j_now.q, lane, rssi, snr);
         } else {  // a window that reaches outside the stream: the fp32 path with its per-sample checks
-            rd_rssi_u8(v, (long)call * cfg.B, cfg, (long)q, lane, rssi, snr);
+            rd_rssi_u8(view(stream), (long)call * cfg.B, cfg, (long)q, lane, rssi, snr);
         }
         const uint32_t at = first + r;
         if (lane == 0 && at < rec_cap) {
@@ -1365,17 +1436,17 @@ int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bi
         !ob.smatch || lay.n_streams <= 0)
         return 0;
     rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount);
-    const uint32_t cg = (uint32_t)(lay.n_streams + 7) / 8;
-    hipLaunchKernelGGL((k_classify_ord<14, 80>), dim3(cg), dim3(256), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32), cfg,
+    const uint32_t cg = (uint32_t)(lay.n_streams + RD_ORD_WG_STREAMS - 1) / RD_ORD_WG_STREAMS;
+    hipLaunchKernelGGL((k_classify_ord<14, 80>), dim3(cg), dim3(32 * RD_ORD_WG_STREAMS), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32), cfg,
                        ob.smatch, ob.scount, lay.n_streams, bucket_limit < RD_BUCKET ? bucket_limit : (uint32_t)RD_BUCKET, n_calls,
-                       (rd_otask *)ob.tasks, ob.skept, ob.soff, ob.wgtot, rec_cap, counters);
-    const uint32_t rg = (uint32_t)(lay.n_streams + 3) / 4;
+                       (rd_otask *)ob.tasks, ob.wgtot, counters);
+    const uint32_t rg = (((cg + RD_ORD_SUPER - 1) / RD_ORD_SUPER) * RD_ORD_RSSI_WAVES + 3) / 4;
     if (ev_stop)
         hipExtLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, nullptr, ev_stop, 0, lay, cfg, (const rd_otask *)ob.tasks,
-                              ob.skept, ob.soff, ob.wgtot, lay.n_streams, cfg.nbytes, recs, rec_cap, counters);
+                              ob.wgtot, (int)cg, cfg.nbytes, recs, rec_cap, counters);
     else
-        hipLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_otask *)ob.tasks, ob.skept, ob.soff,
-                           ob.wgtot, lay.n_streams, cfg.nbytes, recs, rec_cap, counters);
+        hipLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_otask *)ob.tasks, ob.wgtot, (int)cg,
+                           cfg.nbytes, recs, rec_cap, counters);
     return 1;
 }
 
@@ -1597,6 +1668,166 @@ void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_w
     const long nw = (n_win_bits + 31) / 32;
     hipLaunchKernelGGL(k_window_update, dim3((unsigned)((nw + 255) / 256), (unsigned)n_streams), dim3(256), 0, st,
                        win_out, win_in, n_win_bits, block, n_block_bits, win_stride, block_stride);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_stream_block: ONE launch per demodulate() call of the streaming handle (py:139-246 for one block per stream).
+// The multi-launch form (copy, three ring copies, memset, demod, fix-up, window update, search, slice, counter copy,
+// event) spends 70 us on launch overheads and idle gaps for 16 KB of input; here one workgroup per stream does it all:
+//   0  roll the raw ring (py:140,154) and take the new block straight from pinned host memory
+//   1  the block's sign bits, EXACTLY (rd_exact_group_dw, one 8-sample group per thread: 8192 samples need no fast path)
+//   2  quantized window = previous block's bits | new bits (py:157,163-166), kept in LDS and written out for the mirrors
+//   3  preamble search over positions 0 .. B (py:171-188, q <= B: py:194)
+//   4  slice + RSSI / SNR, one wave per match (py:190-246), records into mapped host memory
+//   5  per stream: match count, then - behind a system-scope fence - the sequence number the host polls for
+// Production shape class only (compile-time S, P, K; buffer_length = 2 block_size; block_size a multiple of 32, at most
+// 16384): everything else keeps the multi-launch form.  Every position 0 .. B can be a match (a degenerate input makes
+// it so): the match list in LDS and the stream's region of the mapped record array hold B + 1 entries.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rd_lds_bits32(const uint32_t *w, int nwords, int o) {  // bits o .. o+31 (zeros outside)
+    if (o < 0) return o <= -32 ? 0u : (w[0] << (-o));
+    const int wi = o >> 5;
+    const uint32_t lo = wi < nwords ? w[wi] : 0u, hi = wi + 1 < nwords ? w[wi + 1] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(o & 31));
+}
+
+template <int S_, int P_, uint64_t PRE_, int K_>
+__global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sb_lds[];
+    const int B = a.cfg.B, nwin = (2 * B) / 32, nbw = B / 32;
+    uint8_t *s_iq = sb_lds;                                      // samples -16 .. B-1 as bytes: 32 + 2 B
+    uint32_t *s_win = (uint32_t *)(sb_lds + 32 + 2 * (size_t)B);  // the 2 B-bit window
+    int32_t *s_match = (int32_t *)(s_win + nwin);                // B + 1 positions
+    __shared__ uint32_t s_nm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stream = blockIdx.x;
+    uint8_t *ring = a.ring + (size_t)stream * a.ring_stride;     // [hdr 32 B][previous block][newest block]
+    const uint8_t *in = a.in + (size_t)stream * 2 * (size_t)B;
+    const bool have_hist = a.seen_before > 0;
+    if (tid == 0) s_nm = 0;
+    // ---- 0: the roll.  Every load first (two 16-byte pieces per thread cover 2 B <= 32 KiB), then a barrier, then the
+    // stores: the old newest block is read whole before it is overwritten, the old previous block's tail before the old
+    // newest block lands on it.
+    const int pieces = (2 * B) / 16;
+    uint4 nw[2], oc[2], ph = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = tid + RD_SB_THREADS * k;
+        nw[k] = uint4{0, 0, 0, 0}; oc[k] = uint4{0, 0, 0, 0};
+        if (i < pieces) {
+            nw[k] = *(const uint4 *)(in + 16 * (size_t)i);  // pinned host memory
+            if (have_hist) oc[k] = *(const uint4 *)(ring + 32 + 2 * (size_t)B + 16 * (size_t)i);
+        }
+    }
+    if (have_hist && tid < 2) ph = *(const uint4 *)(ring + 2 * (size_t)B + 16 * (size_t)tid);  // last 32 bytes of the old previous block
+    // the previous block's bits: the upper half of the old window becomes the lower half of the new one
+    const uint32_t *win_in = a.win_in + (size_t)stream * nwin;
+    uint32_t *win_out = a.win_out + (size_t)stream * nwin;
+    uint32_t oldw = 0;
+    if (tid < nbw) oldw = win_in[nbw + tid];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = tid + RD_SB_THREADS * k;
+        if (i < pieces) {
+            *(uint4 *)(ring + 32 + 2 * (size_t)B + 16 * (size_t)i) = nw[k];
+            *(uint4 *)(s_iq + 32 + 16 * (size_t)i) = nw[k];
+            if (have_hist) {
+                *(uint4 *)(ring + 32 + 16 * (size_t)i) = oc[k];
+                if (i >= pieces - 2) *(uint4 *)(s_iq + 16 * (i - (pieces - 2))) = oc[k];  // samples -16 .. -1
+            }
+        }
+    }
+    if (have_hist && tid < 2) *(uint4 *)(ring + 16 * (size_t)tid) = ph;
+    if (!have_hist && tid < 2) *(uint4 *)(s_iq + 16 * tid) = uint4{0, 0, 0, 0};
+    if (tid < nbw) s_win[tid] = oldw;
+    __syncthreads();
+    // ---- 1: exact sign bits, one 8-sample group per thread (dsp.py:38-98 in exact integer arithmetic) ----
+    const long vfrom = have_hist ? -16 : 0;  // (ten samples of history are all a group needs)
+    for (int g = tid; g < B / 8; g += RD_SB_THREADS) {
+        const int t0 = 8 * g;
+        uint32_t dw[10];
+#pragma unroll
+        for (int d = 0; d < 10; d++) {
+            const int smp = t0 - 10 + 2 * d;  // first sample of the dword
+            dw[d] = (smp + 1 >= -16 && smp + 1 < B) ? *(const uint32_t *)(s_iq + 32 + 2 * smp) : 0u;
+        }
+        ((uint8_t *)(s_win + nbw))[g] = (uint8_t)rd_exact_group_dw(dw, (long)t0, 8, vfrom);
+    }
+    __syncthreads();
+    // ---- 2: the window goes out for the state mirrors (rd_copy_quantized) and the next call ----
+    for (int i = tid; i < nwin; i += RD_SB_THREADS) win_out[i] = s_win[i];
+    // ---- 3: search, one 32-position word per thread; positions 0 .. B ----
+    for (int o = tid; o <= nbw; o += RD_SB_THREADS) {
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < P_; k++) {
+            const uint32_t v = rd_lds_bits32(s_win, nwin, 32 * o + k * S_);
+            m &= ((PRE_ >> k) & 1) ? v : ~v;
+        }
+        if (o == nbw) m &= 1u;  // position B only
+        while (m) {
+            const int bpos = __builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t slot = atomicAdd(&s_nm, 1u);
+            s_match[slot] = 32 * o + bpos;  // (at most B + 1 of them)
+        }
+    }
+    __syncthreads();
+    const uint32_t nm = s_nm;
+    // ---- 4: slice + RSSI / SNR, one wave per match (k_slice_rssi's logic for batch_mode = 0) ----
+    rd_packet *recs = a.recs_host + (size_t)stream * (size_t)(B + 1);
+    rd_stream_view v;
+    v.base = ring + 32 + 2 * (size_t)B;
+    v.valid_from = a.seen_before <= 0 ? 0 : a.seen_before == 1 ? -(long)B : -(long)(B + 16);
+    v.n = B;
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the ring stores above are read below (same CU)
+        for (uint32_t i = (uint32_t)wave; i < nm; i += RD_SB_THREADS / 64) {
+            const int pos = __builtin_amdgcn_readfirstlane(s_match[i]);
+            uint32_t byte = 0;
+            bool same_prev = true, same_next = true;
+            for (int r = 0; r * 64 < K_; r++) {
+                const int k = 64 * r + lane;
+                const uint32_t tri = k < K_ ? rd_lds_bits32(s_win, nwin, pos - 1 + k * S_) : 0u;
+                const uint64_t mp = __ballot((tri & 1u) != 0), mm = __ballot((tri & 2u) != 0), mn = __ballot((tri & 4u) != 0);
+                same_prev &= mp == mm;
+                same_next &= mn == mm;
+                const int bi = lane - 8 * r;
+                if (bi >= 0 && bi < 8) {
+                    const int have = K_ - 8 * lane;
+                    const uint32_t rev = __builtin_bitreverse32((uint32_t)((mm >> (8 * bi)) & 0xFF)) >> 24;
+                    byte = have >= 8 ? rev : have > 0 ? rev >> (8 - have) : 0u;
+                }
+            }
+            const uint32_t phs = (uint32_t)pos % (uint32_t)S_;
+            const bool prev_first = S_ == 1 || phs != 0, next_first = S_ > 1 && phs == S_ - 1;
+            const bool superseded = (same_prev && pos >= 1 && prev_first) || (same_next && pos + 1 <= B && next_first);
+            if (superseded) {
+                rd_store_void(nullptr, &recs[i], lane);
+                continue;
+            }
+            double rssi = 0.0, snr = 0.0;
+            rd_rssi_u8(v, 0, a.cfg, (long)pos, lane, rssi, snr);
+            rd_store_record(nullptr, &recs[i], lane, stream, (long)a.seen_before, (long)pos, a.cfg.nbytes, byte, rssi, snr);
+        }
+    }
+    // ---- 5: count, fence, flag ----
+    __syncthreads();
+    if (tid == 0) {
+        a.cnt_host[stream] = nm;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: records and count before the flag
+        __hip_atomic_store(&a.flag_host[stream], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st) {
+    const rd_devcfg &c = a.cfg;
+    if (!(c.S == 14 && c.P == 16 && c.K == 80 && c.pre_mask == 0x91D3ull) || c.L != 2 * c.B || c.B % 32 || c.B < 2048 || c.B > 16384)
+        return 0;
+    const size_t lds = 32 + 2 * (size_t)c.B + (size_t)(2 * c.B / 32) * 4 + ((size_t)c.B + 1) * 4;
+    hipLaunchKernelGGL((k_stream_block<14, 16, 0x91D3ull, 80>), dim3((unsigned)n_streams), dim3(RD_SB_THREADS), lds, st, a);
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------------

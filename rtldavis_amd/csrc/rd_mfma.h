@@ -141,3 +141,50 @@ constexpr rd_mf_taps rd_mf_make_taps() {
             }
     return t;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 8-output formulation (RD_OPT_B8): both digits of a tap in ONE 32-row tile, two k-steps per block.
+// A block of 8 outputs needs a window of 8 + 8 samples = 32 bytes = two 16-byte k-steps (the 16-output block above needs
+// 48 bytes = three), and its 32 rows are 8 outputs x {re, im} x {hi digit, lo digit}: TWO MFMAs per 8 outputs and 32
+// columns instead of six per 16 - a third fewer matrix instructions per sample, one accumulator tuple instead of two,
+// two tap fragments instead of six.  Row R of the tile lands in lane half (R >> 2) & 1, register rho = (R & 3) + 4 (R >> 3);
+// rho = 8 dig + 2 r' + comp and the output is p = 4 half + r': a lane holds re / im and both digits of FOUR consecutive
+// outputs, g[a0 + 8 b + 4 h + 1 + r'], r' = 0..3 (a0 = first sample of column n, b = block 0..7, h = lane half), and
+// G = 2048 * acc[2 r' + comp] + acc[8 + 2 r' + comp] as before.  The hi rows start at -D_hi, the lo rows at 0 (one constant
+// C tuple).  Exactness: unchanged - every row is one digit's sum.
+struct alignas(16) rd_mf_taps8 {
+    uint16_t v[2][64][8];  // [k-step d of a block][lane][element j] as f16 bit patterns
+};
+
+// window byte w (block-relative, 0..31) in row R
+constexpr int rd_mf8_coef(int R, int w, int *dig_out) {
+    const int half = (R >> 2) & 1, rho = (R & 3) + 4 * (R >> 3);
+    const int dig = rho >> 3, r = (rho & 7) >> 1, comp = rho & 1, p = 4 * half + r;
+    *dig_out = dig;
+    const int m = (w >> 1) - p, isq = w & 1;
+    if (m < 0 || m > 8) return 0;
+    const int T[5] = {RD_MF_T0, RD_MF_T1, RD_MF_T2, RD_MF_T3, RD_MF_T4};
+    const int t = T[m <= 4 ? m : 8 - m];
+    const int ph = m & 3;
+    int sgn = 0;
+    if (comp == 0) sgn = isq ? (ph == 1 ? -1 : ph == 3 ? 1 : 0) : (ph == 0 ? 1 : ph == 2 ? -1 : 0);
+    else sgn = isq ? (ph == 0 ? 1 : ph == 2 ? -1 : 0) : (ph == 1 ? 1 : ph == 3 ? -1 : 0);
+    return sgn * t;
+}
+
+constexpr rd_mf_taps8 rd_mf_make_taps8() {
+    rd_mf_taps8 t = {};
+    for (int d = 0; d < 2; d++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 8; j++) {
+                const int R = lane & 31, hk = lane >> 5;
+                const int w = 16 * d + 8 * hk + RD_MF_ELEM(j);
+                int dig = 0;
+                const int c = rd_mf8_coef(R, w, &dig);
+                const int a = c < 0 ? -c : c;
+                const int hi = (a + 1024) >> 11, lo = a - hi * 2048;
+                const int v = dig == 0 ? hi : lo;
+                t.v[d][lane][j] = rd_mf_f16_of_int(c < 0 ? -v : v);
+            }
+    return t;
+}

@@ -118,3 +118,46 @@ def threshold(F: np.ndarray) -> np.ndarray:
     F = F.astype(np.float32)
     return ((F * (np.float32(4.0) * np.float32(E0) + np.float32(4.76837158e-7) * F) + np.float32(3.0e-10))
             * np.float32(1.000001))
+
+
+# ---- the 8-output formulation (RD_OPT_B8, rd_mfma.h): both digits in the rows, two k-steps per block ----
+def taps8_from_lib() -> np.ndarray:
+    """[k-step][lane][element] as float64 (decoded f16)."""
+    from rtldavis_amd import _lib
+    raw = np.zeros(2 * 64 * 8, dtype=np.uint16)
+    _lib.lib().rd_debug_mfma_taps8(raw.ctypes.data)
+    return raw.view(np.float16).astype(np.float64).reshape(2, 64, 8)
+
+
+def model_tile8(win: np.ndarray, taps8: np.ndarray) -> np.ndarray:
+    """One tile through the B8 lane maps: lane (n, h), block b = 0..7 holds - in registers 2 r' + comp (hi digit) and
+    8 + 2 r' + comp (lo digit) - output t = 64 n + 8 b + 4 h + 1 + r', r' = 0..3.  Block b's window = chunks b, b + 1
+    (16 bytes each) of the column's 144-byte window; the hi rows start at -DHI."""
+    assert win.size == 16 + 2 * TILE
+    u = win.astype(np.float64)
+    out = np.zeros(TILE, dtype=np.complex128)
+    lanes = np.arange(64)
+    n, h = lanes & 31, lanes >> 5
+    amats = []
+    for d in range(2):
+        amat = np.zeros((32, 16))
+        for lane in lanes:
+            amat[lane & 31, 8 * (lane >> 5): 8 * (lane >> 5) + 8] = taps8[d, lane]
+        amats.append(amat)
+    for b in range(8):
+        acc = np.zeros((32, 32))
+        for d in range(2):
+            bmat = np.zeros((16, 32))
+            for lane in lanes:
+                for j in range(8):
+                    bmat[8 * h[lane] + j, n[lane]] = u[128 * n[lane] + 16 * (b + d) + 8 * h[lane] + ELEM[j]]
+            acc += amats[d] @ bmat
+        for lane in lanes:
+            for reg in range(8):
+                row_hi = (reg & 3) + 8 * (reg >> 2) + 4 * h[lane]
+                row_lo = ((reg + 8) & 3) + 8 * ((reg + 8) >> 2) + 4 * h[lane]
+                r, comp = reg >> 1, reg & 1
+                t = 64 * n[lane] + 8 * b + 4 * h[lane] + 1 + r
+                v = 2048.0 * (acc[row_hi, n[lane]] - DHI) + acc[row_lo, n[lane]]
+                out[t - 1] += v * (1j if comp else 1)
+    return out

@@ -105,3 +105,37 @@ def test_guard_band_covers_every_mismatch():
         assert not np.any(mism & ~flagged_group[grp]), "a wrong sign outside the guard band"
         total_flagged += int(flagged_group.sum())
     assert total_flagged > 0  # the +-1 LSB case does hit exact zeros
+
+
+def test_b8_rows_are_f16_exact_and_every_row_sum_stays_below_2_24():
+    """The 8-output formulation (RD_OPT_B8): a row of the 32-row tile is ONE digit of one output component, so the
+    exactness argument is the 16-output formulation's, row by row."""
+    taps8 = M.taps8_from_lib()
+    assert np.all(taps8 == np.rint(taps8)) and np.abs(taps8).max() <= 2048
+    rows = np.zeros(32)
+    for d in range(2):
+        for lane in range(64):
+            rows[lane & 31] += np.abs(taps8[d, lane]).sum()
+    assert rows.max() * 255 + M.DHI < 2 ** 24, rows.max() * 255
+    # register rho of a lane half: rho < 8 hi digit, rho >= 8 lo digit of the same (output, component)
+    for half in range(2):
+        for rho in range(8):
+            r_hi = (rho & 3) + 8 * (rho >> 2) + 4 * half
+            r_lo = ((rho + 8) & 3) + 8 * ((rho + 8) >> 2) + 4 * half
+            row_hi = np.concatenate([taps8[d, r_hi + 32 * hk] for d in range(2) for hk in range(2)])
+            row_lo = np.concatenate([taps8[d, r_lo + 32 * hk] for d in range(2) for hk in range(2)])
+            full = 2048 * row_hi + row_lo
+            assert set(np.unique(np.abs(full)).astype(np.int64)) <= {0, *M.T}
+            assert np.count_nonzero(full) == 9  # the nine taps of one output component
+
+
+def test_b8_lane_maps_reproduce_the_direct_filter():
+    rng = np.random.default_rng(6)
+    taps8 = M.taps8_from_lib()
+    for trial in range(3):
+        raw = rng.integers(0, 256, size=16 + 2 * M.TILE, dtype=np.uint8)
+        if trial == 1:
+            raw[:] = rng.choice(np.array([0, 255], dtype=np.uint8), size=raw.size)
+        got = M.model_tile8(raw, taps8)
+        want = M.g_direct(raw[16:], np.concatenate([np.full(2, 127, np.uint8), raw[:16]]))
+        assert np.array_equal(got, want[1: M.TILE + 1]), trial

@@ -57,6 +57,16 @@ for mode in ("demodulate", "submit/fetch"):
         n += sum(len(x) for x in md.fetch())
     dt = time.perf_counter() - t0
     print(f"{NS} receivers, {mode}: {33 / dt:.0f} rounds/s = {33 * NS * B / dt / 1e6:.1f} MS/s ({1e3 * dt / 33:.3f} ms per round), {n} packets")
+# per-call latency of the 16-receiver round
+md.reset()
+tr = []
+for rep in range(4):
+    md.reset()
+    for b in range(33):
+        t0 = time.perf_counter(); md.demodulate(raws[:, 2 * B * b: 2 * B * (b + 1)]); tr.append(time.perf_counter() - t0)
+tr = np.array(tr[5:]) * 1e3
+print(f"{NS} receivers, demodulate(): median {np.median(tr):.3f} ms, p99 {np.percentile(tr, 99):.3f} ms per round "
+      f"(form: {os.environ.get('RD_STREAM_IMPL', 'one launch per block')})")
 t0 = time.perf_counter(); d = dem.discriminated; t1 = time.perf_counter()
 print(f".discriminated materialisation {1e3*(t1-t0):.3f} ms")
 for _ in range(2):
