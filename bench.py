@@ -63,6 +63,10 @@ def parse_args():
     ap.add_argument("--resident", type=int, default=2,
                     help="resident copies of the batch demodulated round-robin (>= 2): runs queued ahead of the host; "
                          "3 and 4 measured no better than 2 (profiles/r02_readback_sdma.txt)")
+    ap.add_argument("--pipelined", type=int, default=0,
+                    help="1: rd_batch_set_pipelined on every resident batch - a run's completion rides on the next run's "
+                         "demod kernel instead of an event on its own last kernel (no idle gap between runs; use with "
+                         "--resident 3 so that the host stays a whole step ahead)")
     ap.add_argument("--stage-times", action="store_true", help="time every kernel stage (adds events)")
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "
@@ -284,6 +288,9 @@ def main():
     t_h2d = time.perf_counter() - t_h2d
     for x in bds[1:]:
         x.upload(host)
+    if args.pipelined:
+        for x in bds:
+            x.set_pipelined(True)
     in_bytes = host.nbytes
     del host
 
@@ -449,9 +456,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_demod_bits" if os.environ.get("RD_K1_IMPL", "").startswith("v") else "k_demod_mfma",
                          "kernel_ms": round(dm, 4), "algorithmic_bytes_per_launch": samples_step * 2},
-            "kernels_ms": {k[:-3]: round(float(tm[k]), 4)
+            "kernels_ms": {k[:-3]: (round(float(tm[k]), 4) if tm[k] > 0 else None)   # (pipelined runs: no end-of-run event)
                            for k in (("demod_ms", "fixup_ms", "search_ms", "slice_ms", "total_ms") if args.stage_times
                                      else ("demod_ms", "total_ms"))},
+            "completion": "pipelined" if args.pipelined else "per run",
             "fixup_runs_frac": round(cnt["fixup_runs"] * 32 / (n_streams * n_samples), 5),
             "packets_per_step": len(recs), "verified_vs_reference_fixtures": verified,
             "h2d_s": round(t_h2d, 3),

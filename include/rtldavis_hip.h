@@ -184,6 +184,15 @@ int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n);
  * far and starts a new window (stages not timed read 0). */
 int rd_batch_set_timing(rd_batch *b, int enabled);
 int rd_batch_get_timing(rd_batch *b, rd_timing *out);
+/* Pipelined completion (opt-in; no counterpart in the reference, whose demodulate() py:128-253 returns its packets
+ * synchronously).  enabled = 1: rd_batch_run ends without an event of its own; the run's readback is hung on the
+ * stop event of the NEXT demod kernel launched on the same HIP stream, by this handle or any other - an event on a
+ * run's last kernel idles the stream for 6-11 us, one on the demod kernel does not.  For callers that keep several
+ * runs queued on one stream (bench.py: resident batches demodulated round-robin): a run's results are ready one
+ * demod kernel later, the stream never idles.  If nothing is launched behind a run, the first call that needs its
+ * results (rd_batch_results, rd_batch_get_timing, ...) records the event then.  A timed pipelined run has no
+ * end-of-run event: rd_timing.total_ms covers the runs that have one (0 if none).  0 (default): off. */
+int rd_batch_set_pipelined(rd_batch *b, int enabled);
 /* Counters of the last run: 32-sample runs with at least one 8-sample group re-evaluated
  * exactly (guard band), raw preamble matches. */
 int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t *matches);

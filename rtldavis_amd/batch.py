@@ -37,10 +37,15 @@ class BatchDemodulator:
         self._cap = 0
         self._recs = None
 
+    def close(self) -> None:
+        """Free the device buffers now (waits for a run still in flight); the object cannot be used afterwards."""
+        if self._b:
+            b, self._b = self._b, None
+            _lib.lib().rd_batch_destroy(b)
+
     def __del__(self):
         try:
-            if self._b:
-                _lib.lib().rd_batch_destroy(self._b)
+            self.close()
         except Exception:
             pass
 
@@ -85,6 +90,11 @@ class BatchDemodulator:
     def set_timing(self, level) -> None:
         """0/False: off; 1/True: demod kernel + whole run (3 events); 2: every stage (5 events)."""
         _lib.check(_lib.lib().rd_batch_set_timing(self._b, int(level)))
+
+    def set_pipelined(self, enabled=True) -> None:
+        """Pipelined completion (include/rtldavis_hip.h: rd_batch_set_pipelined): for several runs kept queued on one
+        stream; a run's results are ready one demod kernel later and the stream never idles between runs."""
+        _lib.check(_lib.lib().rd_batch_set_pipelined(self._b, 1 if enabled else 0))
 
     def timing(self) -> dict:
         t = _lib.RdTiming()

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 
 #include <chrono>
 
@@ -289,7 +291,17 @@ struct rd_batch {
     bool ord_ok = false, ord_run = false, ord_off = false;
     uint32_t bucket_limit = RD_BUCKET;
     size_t cnt_stride = RD_CNT_TOTAL;  // words per counter set (the per-stream match counters live behind the counters)
+    // Pipelined completion (rd_batch_set_pipelined): the run's last kernel carries no event; the readback is hung on
+    // the stop event of the NEXT demod kernel launched on the same stream (any handle's), see batch_adopt below.
+    bool pipelined = false;
+    bool deferred = false;          // the run in flight has no completion event yet (guarded by g_tail_mx)
+    hipEvent_t kfirst = nullptr;    // stop event of this handle's demod launch when it adopts another run untimed
+    std::vector<uint8_t> ev_end;    // per timed run: its end-of-run event (ev[4]) was recorded
 };
+
+// pipelined completion: launch stream -> the handle whose last run waits there for an adopter (see batch_adopt)
+static std::mutex g_tail_mx;
+static std::unordered_map<hipStream_t, rd_batch *> g_tail;
 
 static rd_layout batch_layout(const rd_batch *b) {
     rd_layout l;
@@ -387,6 +399,7 @@ static int batch_alloc(rd_batch *b) {
     b->rec_pin_cap = b->rec_cap;
     HIPCHK(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&b->kdone, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b->kfirst, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     b->dev_ready = true;
     return RD_OK;
@@ -394,8 +407,15 @@ static int batch_alloc(rd_batch *b) {
 
 extern "C" void rd_batch_destroy(rd_batch *b) {
     if (!b) return;
+    {
+        std::lock_guard<std::mutex> g(g_tail_mx);  // a run still waiting to be adopted dies with its handle
+        auto it = g_tail.find(b->stream);
+        if (it != g_tail.end() && it->second == b) g_tail.erase(it);
+        b->deferred = false;
+    }
     if (b->dev_ready && g_hip_pid == getpid()) {
         if (b->device >= 0) hipSetDevice(b->device);
+        if (b->ran && !b->fetched) hipDeviceSynchronize();  // kernels of a run nobody fetched may still use the buffers
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
@@ -403,6 +423,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
+        if (b->kfirst) hipEventDestroy(b->kfirst);
         if (b->copy_stream) hipStreamDestroy(b->copy_stream);
         for (auto &e : b->evs) if (e) hipEventDestroy(e);
     }
@@ -430,13 +451,70 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
     return RD_OK;
 }
 
-// search + slice part of a run (re-issued on list overflow)
-static int batch_search_slice(rd_batch *b, hipStream_t st) {
+// results come back with the run: counters plus as many records as the last run produced
+// (+25 %); rd_batch_results fetches the remainder if this run produced more.
+// The copies run on their own stream so that another batch's kernels queued on `st` need
+// not wait for them.
+static int batch_readback(rd_batch *b, hipEvent_t after) {
+    HIPCHK(hipStreamWaitEvent(b->copy_stream, after, 0));
+    HIPCHK(hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          b->copy_stream));
+    const uint32_t spec = std::min(b->ord_run ? b->rec_cap : b->match_cap, b->spec_recs);
+    if (spec)
+        HIPCHK(hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
+                              b->copy_stream));
+    HIPCHK(hipEventRecord(b->done, b->copy_stream));
+    return RD_OK;
+}
+
+// Pipelined completion.  An event on a run's last kernel leaves the GPU idle for 6-11 us before the next kernel
+// starts (profiles/r02_event_gap.txt); an event on the demod kernel costs nothing measurable (the fix-up kernel
+// starts as it ends).  A pipelined handle therefore launches its tail without an event and waits to be ADOPTED: the
+// next run launched on the same stream - this handle's or another's - gives its demod kernel a stop event and the
+// adopted run's readback waits for that one (kernels of a stream run in order: when the next demod kernel has ended,
+// the adopted run's tail has).  The records arrive one demod kernel later; the stream never idles.  If nothing is
+// launched behind it, the first call that needs the results records an event on the stream as before.
+// g_tail: launch stream -> the handle waiting there; every transition of `deferred` happens under g_tail_mx (the
+// adopter may be another thread's handle).
+
+static int batch_flush_locked(rd_batch *p) {  // nobody adopted it: an event of its own
+    if (!p->deferred) return RD_OK;
+    auto it = g_tail.find(p->stream);
+    if (it != g_tail.end() && it->second == p) g_tail.erase(it);
+    p->deferred = false;
+    int rc = use_device(p->device);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(p->kdone, p->stream));
+    return batch_readback(p, p->kdone);
+}
+static int batch_flush(rd_batch *b) {
+    std::lock_guard<std::mutex> g(g_tail_mx);
+    return batch_flush_locked(b);
+}
+static bool batch_stream_has_tail(hipStream_t st) {
+    std::lock_guard<std::mutex> g(g_tail_mx);
+    return g_tail.find(st) != g_tail.end();
+}
+// `carrier`: recorded when a kernel launched on `st` after the waiting run's tail has ended
+static int batch_adopt(hipStream_t st, hipEvent_t carrier) {
+    std::lock_guard<std::mutex> g(g_tail_mx);
+    auto it = g_tail.find(st);
+    if (it == g_tail.end()) return RD_OK;
+    rd_batch *p = it->second;
+    g_tail.erase(it);
+    p->deferred = false;
+    return batch_readback(p, carrier);
+}
+
+// search + slice part of a run (re-issued on list overflow: then with an event of its own, may_defer = false)
+static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = false) {
     const rd_layout lay = batch_layout(b);
     const long B = b->dc.B, L = b->dc.L;
-    // the run's last kernel carries the end-of-run event itself when nothing follows it
-    hipEvent_t last = b->run_timing ? b->ev[4] : b->kdone;
     const bool last_on_slice = !b->parse;
+    const bool defer = may_defer && b->pipelined && last_on_slice && !(b->run_timing && b->run_detail);
+    // the run's last kernel carries the end-of-run event itself when nothing follows it
+    hipEvent_t last = defer ? nullptr : b->run_timing ? b->ev[4] : b->kdone;
+    if (b->run_timing && may_defer) b->ev_end.push_back(defer ? 0 : 1);
     b->ord_run = false;
     if (b->ord_ok && !b->ord_off && !(b->run_timing && b->run_detail)) {
         rd_ord_bufs ob = b->ord;
@@ -458,20 +536,23 @@ static int batch_search_slice(rd_batch *b, hipStream_t st) {
         if (!b->d_parsed) HIPCHK(hipMalloc(&b->d_parsed, (size_t)b->rec_cap * sizeof(rd_parsed)));
         rd_launch_parse(lay, b->dc, b->d_recs, b->match_cap, b->d_parsed, batch_cnt(b), st, b->dense);
     }
-    // results come back with the run: counters plus as many records as the last run produced
-    // (+25 %); rd_batch_results fetches the remainder if this run produced more.
-    // The copies run on their own stream so that another batch's kernels queued on `st` need
-    // not wait for them.  Every event recorded between two kernels idles the GPU for a few
-    // microseconds, so a timed run's end-of-run event doubles as the copy stream's trigger.
+    if (defer) {  // the readback is enqueued by whoever launches next on this stream (batch_adopt) or by batch_flush
+        std::lock_guard<std::mutex> g(g_tail_mx);
+        auto it = g_tail.find(st);
+        if (it != g_tail.end() && it->second != b) {  // (cannot happen after rd_batch_run's adoption; kept safe)
+            int rc = batch_flush_locked(it->second);
+            if (rc) return rc;
+        }
+        g_tail[st] = b;
+        b->deferred = true;
+        HIPCHK(hipGetLastError());
+        return RD_OK;
+    }
+    // Every event recorded between two kernels idles the GPU for a few microseconds, so a timed run's end-of-run
+    // event doubles as the copy stream's trigger.
     if (!last_on_slice) HIPCHK(hipEventRecord(last, st));
-    HIPCHK(hipStreamWaitEvent(b->copy_stream, last, 0));
-    HIPCHK(hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                          b->copy_stream));
-    const uint32_t spec = std::min(b->ord_run ? b->rec_cap : b->match_cap, b->spec_recs);
-    if (spec)
-        HIPCHK(hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
-                              b->copy_stream));
-    HIPCHK(hipEventRecord(b->done, b->copy_stream));
+    int rc = batch_readback(b, last);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     return RD_OK;
 }
@@ -485,7 +566,11 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     const rd_layout lay = batch_layout(b);
     // the previous run's readback of d_cnt / d_recs must be over before they are rewritten: the host
     // has already waited for it if the results were fetched (the normal order), else the stream waits
-    if (b->ran && !b->fetched) HIPCHK(hipStreamWaitEvent(st, b->done, 0));
+    if (b->ran && !b->fetched) {
+        rc = batch_flush(b);  // (a pipelined run nobody adopted: its readback is not even enqueued yet)
+        if (rc) return rc;
+        HIPCHK(hipStreamWaitEvent(st, b->done, 0));
+    }
     b->fetched = false;
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;
@@ -501,17 +586,24 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         b->ev = &b->evs[5 * b->ev_runs];
         b->ev_runs++;
     }
+    // a pipelined run waiting on this stream is adopted by this run's demod kernel (its stop event)
+    const bool adopt = batch_stream_has_tail(st);
     if (b->timing && b->fast_ok) {
         // the demod kernel's dispatch carries its own start / stop events (no marker packets)
         rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1]);
+        if (adopt && (rc = batch_adopt(st, b->ev[1]))) return rc;
+    } else if (b->fast_ok && adopt) {
+        rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst);
+        if ((rc = batch_adopt(st, b->kfirst))) return rc;
     } else {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
         if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
+        if (adopt && (rc = batch_adopt(st, b->ev[1] ))) return rc;
     }
     rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
-    rc = batch_search_slice(b, st);
+    rc = batch_search_slice(b, st, true);
     if (rc) return rc;
     b->ran = true;
     return RD_OK;
@@ -521,6 +613,10 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
 static int batch_finish(rd_batch *b) {
     if (!b->ran) return fail(RD_ERR_STATE, "rd_batch_run has not been called");
     hipStream_t st = b->stream;
+    {
+        int frc = batch_flush(b);  // pipelined and not adopted: nothing was launched behind this run
+        if (frc) return frc;
+    }
     for (int attempt = 0; attempt < 8; attempt++) {
         const double ta = now_ms();
         int wrc = wait_event(b->done);
@@ -708,11 +804,21 @@ extern "C" int rd_batch_parsed(rd_batch *b, rd_parsed *out, int cap, int *n) {
     return RD_OK;
 }
 
+// 1: pipelined completion (see batch_adopt): for callers that keep several runs queued on one stream and want the
+// stream never to idle; a run's results then become available one demod kernel later.  0 (default): every run ends
+// with an event of its own.
+extern "C" int rd_batch_set_pipelined(rd_batch *b, int enabled) {
+    if (!b) return fail(RD_ERR_ARG, "null batch");
+    b->pipelined = enabled != 0;
+    return RD_OK;
+}
+
 extern "C" int rd_batch_set_timing(rd_batch *b, int enabled) {
     if (!b) return fail(RD_ERR_ARG, "null batch");
     b->timing = enabled != 0;
     b->timing_detail = enabled >= 2;  // 1: demod kernel and total only (3 events per run); 2: every stage
     b->ev_runs = 0;
+    b->ev_end.clear();
     // events for the first 64 timed runs exist before the first of them is launched (creating them one run at a
     // time showed as a stall of several milliseconds inside a 60 ms timed region)
     if (b->timing && b->dev_ready && use_device(b->device) == RD_OK) {
@@ -734,6 +840,7 @@ extern "C" int rd_batch_get_timing(rd_batch *b, rd_timing *out) {
     // mean over the runs recorded since the last call (events are only read here, after the
     // timed region: hipEventElapsedTime costs milliseconds on ROCm 7.2)
     rd_timing t = {};
+    size_t n_end = 0;
     for (size_t r = 0; r < b->ev_runs; r++) {
         hipEvent_t *e = &b->evs[5 * r];
         float v[5] = {0, 0, 0, 0, 0};
@@ -743,15 +850,19 @@ extern "C" int rd_batch_get_timing(rd_batch *b, rd_timing *out) {
             HIPCHK(hipEventElapsedTime(&v[2], e[2], e[3]));
             HIPCHK(hipEventElapsedTime(&v[3], e[3], e[4]));
         }
-        HIPCHK(hipEventElapsedTime(&v[4], e[0], e[4]));
+        // (a pipelined run has no end-of-run event: total_ms is the mean over the runs that have one, 0 if none)
+        const bool has_end = r >= b->ev_end.size() || b->ev_end[r];
+        if (has_end) { HIPCHK(hipEventElapsedTime(&v[4], e[0], e[4])); n_end++; }
         t.demod_ms += v[0]; t.fixup_ms += v[1]; t.search_ms += v[2]; t.slice_ms += v[3]; t.total_ms += v[4];
     }
     if (b->ev_runs) {
         const float k = 1.0f / (float)b->ev_runs;
-        t.demod_ms *= k; t.fixup_ms *= k; t.search_ms *= k; t.slice_ms *= k; t.total_ms *= k;
+        t.demod_ms *= k; t.fixup_ms *= k; t.search_ms *= k; t.slice_ms *= k;
+        t.total_ms = n_end ? t.total_ms / (float)n_end : 0.0f;
     }
     t.runs = (int32_t)b->ev_runs;
     b->ev_runs = 0;
+    b->ev_end.clear();
     b->last_timing = t;
     *out = t;
     return RD_OK;

@@ -542,6 +542,34 @@ __device__ __forceinline__ void rd_mf_read_window(uint32_t a_prv, uint32_t a_own
                  : "memory");
 }
 
+// RD_OPT_FPROBE (diagnostic library only): the work of an in-tile preamble search, to MEASURE what fusing k_search
+// into this kernel would cost before building the list-driven remainder it would need.  Per tile:
+// the lane's finished word goes to a 72-word ring in LDS (8 words of history + the tile's 64), the lane reads the 8
+// words that end with its own and evaluates the 16 taps of py:171-188 for the 32 positions of the word seven back
+// (15 funnel shifts + the and / or tree, as k_search does for each of its four words), a wave-uniform branch takes the
+// rare match.  The matches go nowhere (the words are not yet fixed up and the tile's first seven words see the
+// previous tile of the WAVE, not of the stream): the timing is the result.
+template <int S_, int P_, uint64_t PRE_>
+__device__ __forceinline__ uint32_t rd_mf_search_probe(uint32_t ring_addr, uint32_t wi, uint32_t word) {
+    rd_lds_write4(ring_addr + 4 * (8 + wi), word);
+    uint32_t r[8];
+    asm volatile("ds_read2_b32 %0, %4 offset0:1 offset1:2\n\tds_read2_b32 %1, %4 offset0:3 offset1:4\n\t"
+                 "ds_read2_b32 %2, %4 offset0:5 offset1:6\n\tds_read2_b32 %3, %4 offset0:7 offset1:8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(*(rd_u2v *)&r[0]), "=&v"(*(rd_u2v *)&r[2]), "=&v"(*(rd_u2v *)&r[4]), "=&v"(*(rd_u2v *)&r[6])
+                 : "v"(ring_addr + 4 * wi) : "memory");
+    uint32_t m = 0xFFFFFFFFu, any = 0;
+#pragma unroll
+    for (int k = 0; k < P_; k++) {
+        const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
+        const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[wj + 1 < 8 ? wj + 1 : 7], r[wj], sh) : r[wj];
+        if ((PRE_ >> k) & 1) m &= v; else any |= v;
+    }
+    m &= ~any;
+    if (wi >= 56) rd_lds_write4(ring_addr + 4 * (wi - 56), word);  // the next tile's history
+    return m;
+}
+
 // In-kernel stamps (RD_OPT_STAMP, diagnostic library only; cdna_hip_programming.md section 7): one statement with
 // its own lgkmcnt(0), fenced against the scheduler on both sides.
 __device__ __forceinline__ uint64_t rd_stamp() {
@@ -570,6 +598,7 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 #define RD_OPT_HALO 2
 #define RD_OPT_STAMP 4
 #define RD_OPT_B8 8   // the 8-output formulation: 16 MFMAs per tile (rd_mf8_tile)
+#define RD_OPT_FPROBE 16  // diagnostic library: what an in-tile preamble test would cost (rd_mf_search_probe)
 #define RD_STAMP_WORDS 12
 template <int DBG, int NBUF, int OPT>
 __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
@@ -837,6 +866,15 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
             const auto w2 = __builtin_amdgcn_permlane32_swap(word, word, false, false);  // [0]: half 0's, [1]: half 1's
             word = __builtin_amdgcn_perm(w2[1], w2[0], psel);
         }
+#ifdef RD_DIAG
+        if constexpr ((OPT & RD_OPT_FPROBE) != 0) {
+            __shared__ uint32_t s_ring[RD_MF_WAVES][72];
+            const uint32_t m = rd_mf_search_probe<14, 16, 0x91D3ull>(rd_lds_addr(s_ring[wave]), (uint32_t)(2 * n + h), word);
+            if (rd_mf_any(m != 0)) {  // rare (2^-16 per position on noise): where the match would be appended
+                if (m) rd_lds_write4(rd_lds_addr(s_ring[wave]) + 4 * 70, m);
+            }
+        }
+#endif
         const bool carry = inchunk > 0 && ti > 0;  // previous iteration = previous tile of this stream
         const uint32_t run = ti * 64 + 2 * n + h;  // word index in the stream
         const uint32_t t0 = run * RD_RUN;
@@ -1061,7 +1099,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
         RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
         RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
         RD_V(10, 1, 0) RD_V(10, 1, 4) RD_V(11, 1, 0) RD_V(11, 1, 4)
-        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10)
+        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10) RD_V(0, 1, 26) RD_V(1, 1, 10) RD_V(2, 1, 10) RD_V(6, 1, 10)
         RD_V(0, 2, 0)
 #undef RD_V
         default:

@@ -1215,13 +1215,15 @@ __global__ __launch_bounds__(32 * RD_ORD_WG_STREAMS) void k_classify_ord(const u
     __shared__ __attribute__((aligned(16))) uint32_t s_t[RD_ORD_WG_STREAMS][RD_BUCKET][8];
     const int lane = threadIdx.x & 63, sub = lane & 31, grp = threadIdx.x >> 5;
     const int stream = blockIdx.x * RD_ORD_WG_STREAMS + grp;
+    // the stream's count and this lane's slot of its bucket are loaded together (a slot past the count holds an old
+    // run's position or nothing: dropped below) - one memory round trip instead of two in front of the word loads
     uint32_t count = stream < n_streams ? scount[stream] : 0u;
+    int pos = stream < n_streams ? smatch[(size_t)stream * RD_BUCKET + sub] : 0;
     const uint32_t nmatch = count;
     const bool ovf = count > bucket_limit;
     if (ovf) count = 0;  // the host runs the unordered path on this input
     const bool live = (uint32_t)sub < count;
-    int pos = 0;
-    if (live) pos = smatch[(size_t)stream * RD_BUCKET + sub];
+    if (!live) pos = 0;
     // the words that hold the packet's symbols: ALL loads issued before the first use (the fence below) - taken a few
     // at a time they cost this kernel a memory latency per batch
     const uint32_t *w = bits + (size_t)(stream < n_streams ? stream : 0) * bits_stride;

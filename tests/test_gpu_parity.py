@@ -857,6 +857,54 @@ def test_ordered_tail_equals_the_unordered_kernels_plus_host_ordering(dsp, batch
 
 
 @pytest.mark.gpu
+def test_pipelined_completion_returns_the_same_packets(dsp, batchmod, golden_streams):
+    """rd_batch_set_pipelined: a run ends without an event of its own and is adopted by the next demod kernel launched
+    on the stream (another handle's or its own).  Three handles with different inputs round-robin on one stream, runs
+    queued ahead as bench.py does; then the paths nobody adopts: the last run of the loop, a single run, two runs in a
+    row without fetching, timing switched on, a handle destroyed with its run still waiting.  Every result = the
+    fixtures' packets (dsp.py:128-253)."""
+    groups = [list(range(0, 6)), list(range(6, 12)), list(range(12, 18))]
+    bds = []
+    for g in groups:
+        bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(g), synth.BLOCKS_PER_STREAM)
+        bd.upload(synth.synth_streams(g))
+        bd.set_pipelined(True)
+        bds.append(bd)
+
+    def check(bd, g):
+        res = bd.packets()
+        for i, seed in enumerate(g):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+
+    R, k = len(bds), 9
+    for i in range(R - 1):
+        bds[i].run()
+    for i in range(k):
+        if i + R - 1 < k:
+            bds[(i + R - 1) % R].run()
+        check(bds[i % R], groups[i % R])      # adopted by the run launched behind it; the last one by nobody
+    bds[0].run()
+    check(bds[0], groups[0])                  # a single run: flushed by results()
+    bds[1].run()
+    bds[1].run()                              # run again without fetching: the first one is flushed by the second
+    check(bds[1], groups[1])
+    for bd in bds:
+        bd.set_timing(1)
+    bds[0].run()
+    bds[1].run()
+    bds[2].run()
+    for bd, g in zip(bds, groups):
+        check(bd, g)
+    tm = [bd.timing() for bd in bds]
+    assert all(t["runs"] == 1 and t["demod_ms"] > 0 for t in tm)
+    assert tm[0]["total_ms"] == 0 and tm[1]["total_ms"] == 0   # adopted: no end-of-run event
+    bds[2].run()
+    bds[2].close()                            # destroyed while waiting for an adopter
+    bds[0].run()
+    check(bds[0], groups[0])
+
+
+@pytest.mark.gpu
 def test_ordered_tail_falls_back_when_a_stream_overflows_its_bucket(dsp, batchmod, golden_streams, monkeypatch):
     """RD_TEST_BUCKET_CAP=2: every stream has more than two matches, the ordered tail raises its overflow flag, and
     rd_batch_results re-runs the unordered kernels on the same bits - the fixtures' packets, twice in a row (the
