@@ -421,18 +421,26 @@ def main():
     # it was measured on: a file that belongs to other kernels is refused.
     traffic, traffic_note = None, None
     try:
+        import glob
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import profile_collect
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
-            tj = json.load(fh)
-        w = tj["workload"]
-        if tj.get("sources_sha256") != profile_collect.sources_sha256():
-            traffic_note = ("profiles/r02_traffic.json was measured on other kernel sources (stamp "
-                            f"{str(tj.get('sources_sha256'))[:12]}, commit {tj.get('commit')}): not used; "
-                            "regenerate with tools/profile_round.sh")
-        elif (w["streams"], w["blocks"], w["block_size"]) == (n_streams, n_blocks, cfg.block_size) \
-                and not os.environ.get("RD_K1_IMPL"):
-            traffic = int(tj["traffic_bytes"])
+        stamp = profile_collect.sources_sha256()
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True)
+        for path in files:  # the newest round's file that was measured on the demod kernel sources in the tree
+            with open(path) as fh:
+                tj = json.load(fh)
+            w = tj["workload"]
+            if tj.get("sources_sha256") != stamp:
+                if traffic_note is None:
+                    traffic_note = (f"profiles/{os.path.basename(path)} was measured on other kernel sources (stamp "
+                                    f"{str(tj.get('sources_sha256'))[:12]}, commit {tj.get('commit')}): not used; "
+                                    "regenerate with tools/profile_round.sh")
+                continue
+            if (w["streams"], w["blocks"], w["block_size"]) == (n_streams, n_blocks, cfg.block_size) \
+                    and not os.environ.get("RD_K1_IMPL"):
+                traffic = int(tj["traffic_bytes"])
+                traffic_note = None
+            break
     except (OSError, KeyError, ValueError, TypeError, ImportError):
         pass
 

@@ -475,6 +475,22 @@ __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t
             const rd_u4v v = rd_lds_read16u(stage_addr + 16 * (lane + 64 * j));
             // non-temporal: the words are read next by another kernel, never again by this one (0.3-1.3 % faster;
             // RD_K1_STFLAGS & 1 switches to plain stores for A/B runs)
+#ifdef RD_DIAG
+            // RD_K1_STFLAGS bits 3-5 (diagnostic library): the store's cache policy bits spelled out - which of them,
+            // if any, changes what the word stores cost beside the tile loads (profiles/r03_store_policy.txt)
+            if ((stflags >> 3) & 7) {
+                rd_u4v *ptr = (rd_u4v *)(base + 4 * (lane + 64 * j));
+                switch ((stflags >> 3) & 7) {
+                    case 1: asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(ptr), "v"(v) : "memory"); break;
+                    case 2: asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory"); break;
+                    case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory"); break;
+                    case 4: asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(ptr), "v"(v) : "memory"); break;
+                    case 5: asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(ptr), "v"(v) : "memory"); break;
+                    default: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(ptr), "v"(v) : "memory"); break;
+                }
+                continue;
+            }
+#endif
             if (!(stflags & 1)) __builtin_nontemporal_store(v, (rd_u4v *)(base + 4 * (lane + 64 * j)));
             else *(rd_u4v *)(base + 4 * (lane + 64 * j)) = v;
         }

@@ -10,14 +10,40 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+DEMOD_KERNEL_SOURCES = ("rd_demod_mfma.hip", "rd_mfma.h", "rd_internal.h", "rd_math.h")
+
+
+def product_view(text: str) -> str:
+    """The source as the product library sees it: `#ifdef RD_DIAG` blocks (diagnostic variants, compiled only into
+    librtldavis_hip_diag.so) dropped, their `#else` branches kept."""
+    out, stack = [], []  # stack entries: [is_diag_block, in_else]
+    for line in text.splitlines():
+        t = line.strip()
+        if t.startswith("#if"):
+            stack.append([t.replace(" ", "") in ("#ifdefRD_DIAG", "#ifdefined(RD_DIAG)"), False])
+            if stack[-1][0]:
+                continue
+        elif t.startswith("#else") and stack and stack[-1][0]:
+            stack[-1][1] = True
+            continue
+        elif t.startswith("#endif") and stack:
+            if stack.pop()[0]:
+                continue
+        if any(d and not e for d, e in stack):
+            continue
+        out.append(line)
+    return "\n".join(out)
+
+
 def sources_sha256() -> str:
-    """Stamp of the kernel sources (what bench.py checks a traffic file against)."""
+    """Stamp of the sources of the dominant kernel, k_demod_mfma (what bench.py checks a traffic file against): the
+    kernel's own file and the headers it includes, as the product library is built from them (product_view).  The
+    tail kernels, the host code and the diagnostic variants may change without the demod kernel's HBM traffic changing."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rtldavis_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as fh:
-                h.update(name.encode() + b"\0" + fh.read())
+    for name in DEMOD_KERNEL_SOURCES:
+        with open(os.path.join(d, name), "r") as fh:
+            h.update(name.encode() + b"\0" + product_view(fh.read()).encode())
     return h.hexdigest()
 
 
