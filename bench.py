@@ -415,26 +415,25 @@ def main():
             raise SystemExit(f"bench.py: GPU output differs from the reference fixtures (rank {rank}: "
                              f"{'ok' if ok else 'MISMATCH'}) - result invalid")
 
-    # HBM traffic of the dominant kernel: measured with PMC counters in a separate rocprofv3 run
-    # (tools/pmc_traffic.sh) and committed under profiles/; valid for the default workload only
-    # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel sources
-    # it was measured on: a file that belongs to other kernels is refused.
+    # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 runs
+    # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel's MACHINE CODE in
+    # the library it was measured on (tools/profile_collect.py::kernel_code_sha256); valid for the default workload
+    # only.  A file that belongs to another build of the kernel is refused.
     traffic, traffic_note = None, None
     try:
         import glob
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import profile_collect
-        stamp = profile_collect.sources_sha256()
+        stamp = profile_collect.kernel_code_sha256(_lib.LIB_PATH)   # the demod kernel's machine code in the library in use
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True)
-        for path in files:  # the newest round's file that was measured on the demod kernel sources in the tree
+        for path in files:  # the newest round's file that was measured on this very kernel code
             with open(path) as fh:
                 tj = json.load(fh)
             w = tj["workload"]
-            if tj.get("sources_sha256") != stamp:
+            if not stamp or tj.get("kernel_code_sha256") != stamp:
                 if traffic_note is None:
-                    traffic_note = (f"profiles/{os.path.basename(path)} was measured on other kernel sources (stamp "
-                                    f"{str(tj.get('sources_sha256'))[:12]}, commit {tj.get('commit')}): not used; "
-                                    "regenerate with tools/profile_round.sh")
+                    traffic_note = (f"profiles/{os.path.basename(path)} was measured on another build of k_demod_mfma "
+                                    f"(commit {tj.get('commit')}): not used; regenerate with tools/profile_round.sh")
                 continue
             if (w["streams"], w["blocks"], w["block_size"]) == (n_streams, n_blocks, cfg.block_size) \
                     and not os.environ.get("RD_K1_IMPL"):

@@ -601,7 +601,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
         if (adopt && (rc = batch_adopt(st, b->ev[1] ))) return rc;
     }
-    rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride);
+    rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
     rc = batch_search_slice(b, st, true);
     if (rc) return rc;

@@ -64,8 +64,10 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
 // zero_words: how many words at zero_next (the counter set, plus the per-stream match counters of the ordered tail
 // when the handle has them behind it)
+// expect (0: unknown): the list length of the handle's previous run - the grid is sized for it (+25 %) instead of
+// for the list's capacity (every lane loops with the grid's stride, so a short grid is only slower, never wrong)
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
-                     uint32_t *zero_next, hipStream_t st, uint32_t zero_words = RD_CNT_TOTAL);
+                     uint32_t *zero_next, hipStream_t st, uint32_t zero_words = RD_CNT_TOTAL, uint64_t expect = 0);
 // Search positions p in [p_lo, p_hi] of every stream's bit array (bits outside [0, n_bits) are 0).
 // smatch / scount (both or neither): the matches go to per-stream buckets instead of the one list (ordered tail)
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,

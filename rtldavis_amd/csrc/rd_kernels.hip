@@ -333,10 +333,13 @@ __global__ __launch_bounds__(256) void k_fixup(rd_layout lay, uint32_t runs_per_
 }
 
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
-                     uint32_t *zero_next, hipStream_t st, uint32_t zero_words) {
+                     uint32_t *zero_next, hipStream_t st, uint32_t zero_words, uint64_t expect) {
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
     if (rps == 0 || lay.n_streams == 0) return;
     uint64_t want = all ? (uint64_t)lay.n_streams * rps : fix_cap;
+    // a list that is 4 % full does not need a grid for all of it: 4096 workgroups of which 3400 find nothing to do
+    // take longer to dispatch than the listed groups take to re-evaluate
+    if (!all && expect > 0) want = std::min<uint64_t>(want, std::max<uint64_t>(expect + expect / 4, 256 * 256));
     uint64_t wgs = (want + 255) / 256;
     if (wgs > 256ull * 16) wgs = 256ull * 16;
     if (wgs == 0) wgs = 1;
@@ -372,7 +375,9 @@ __device__ __forceinline__ uint32_t rd_bits32_at_i(const uint32_t *w, int nwords
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(o & 31));
 }
 
-#define RD_SEARCH_OUT 4     // output words (32 positions each) per lane
+#ifndef RD_SEARCH_OUT
+#define RD_SEARCH_OUT 4     // output words (32 positions each) per lane (a multiple of 4: 16-byte loads)
+#endif
 #define RD_MATCH_PEND 128   // staged matches per wave
 #define RD_SEARCH_WAVES 4    // waves per workgroup (16 was tried to cut the end-of-kernel atomics: no gain)
 #ifndef RD_SEARCH_UNROLL
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
             if (wg >= nwave_groups) break;  // wave-uniform
             const uint32_t s = su[u];
             const int gi = (int)remu[u] * 64 + lane;
-            uint32_t m[RD_SEARCH_OUT] = {0, 0, 0, 0};
+            uint32_t m[RD_SEARCH_OUT] = {};
             int p0 = 0;
             if (gi < gps) {
                 p0 = base_i + 32 * RD_SEARCH_OUT * gi;
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
                 if constexpr (S_ > 0) {
                     // compile-time preamble: all[o] = AND of the taps that must be 1, any[o] = OR of
                     // the taps that must be 0 (two at a time with v_or3_b32); match = all & ~any
-                    uint32_t any[RD_SEARCH_OUT] = {0, 0, 0, 0};
+                    uint32_t any[RD_SEARCH_OUT] = {};
                     uint32_t held[RD_SEARCH_OUT];
                     bool have_held = false;
 #pragma unroll
@@ -536,7 +541,9 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
             if (BKT) {
                 // per-stream buckets: ONE returning atomic per wave-group that found anything (3 in 10 do), for all
                 // four output words of all lanes - a lane's slots follow those of the lanes below it
-                const uint32_t mine = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+                uint32_t mine = 0;
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) mine += (uint32_t)__popc(m[o]);
                 if (__ballot(mine != 0)) {  // wave-uniform
                     uint32_t incl = mine;
 #pragma unroll
@@ -1270,28 +1277,43 @@ __global__ __launch_bounds__(32 * RD_ORD_WG_STREAMS) void k_classify_ord(const u
     maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, 32, 64));
     maxc = __builtin_amdgcn_readfirstlane(maxc);
     // (a half-wave reads what the same wave wrote: LDS operations of a wave complete in order, no barrier needed)
-    // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205)
+    // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205).
+    // Four entries per trip (broadcast reads, all eight issued before the first is used: a trip per entry waited for
+    // the LDS once per entry); the slots past a stream's count hold flags = 0 and match nothing.
     bool dup0 = false, dup1 = false;
-    for (uint32_t j = 0; j < maxc; j++) {
-        const uint4 a = *(const uint4 *)s_t[grp][j], d = *(const uint4 *)(s_t[grp][j] + 4);
-        const int ob0 = (int)a.y;
-        if (d.x == dw[0] && d.y == dw[1] && d.z == dw[2]) {
-            if ((a.x & 1u) && ob0 == b0 && a.z < k0) dup0 = true;
-            if ((a.x & 2u) && ob0 - 1 == b0 && a.w < k0) dup0 = true;
-            if ((a.x & 1u) && ob0 == b1 && a.z < k1) dup1 = true;
-            if ((a.x & 2u) && ob0 - 1 == b1 && a.w < k1) dup1 = true;
+    for (uint32_t j0 = 0; j0 < maxc; j0 += 4) {
+        uint4 a[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = *(const uint4 *)s_t[grp][(j0 + u) & (RD_BUCKET - 1)];
+            d[u] = *(const uint4 *)(s_t[grp][(j0 + u) & (RD_BUCKET - 1)] + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int ob0 = (int)a[u].y;
+            if (d[u].x == dw[0] && d[u].y == dw[1] && d[u].z == dw[2]) {
+                if ((a[u].x & 1u) && ob0 == b0 && a[u].z < k0) dup0 = true;
+                if ((a[u].x & 2u) && ob0 - 1 == b0 && a[u].w < k0) dup0 = true;
+                if ((a[u].x & 1u) && ob0 == b1 && a[u].z < k1) dup1 = true;
+                if ((a[u].x & 2u) && ob0 - 1 == b1 && a[u].w < k1) dup1 = true;
+            }
         }
     }
     const bool kept0 = ok0 && !dup0, kept1 = ok1 && !dup1;
     s_t[grp][sub][0] = (kept0 ? 1u : 0u) | (kept1 ? 2u : 0u);
     // pass 2: rank among the surviving tasks of the stream
     uint32_t r0 = 0, r1 = 0;
-    for (uint32_t j = 0; j < maxc; j++) {
-        const uint4 a = *(const uint4 *)s_t[grp][j];
-        const int ob0 = (int)a.y;
-        auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
-        if (a.x & 1u) { r0 += before(ob0, a.z, b0, k0) ? 1u : 0u; r1 += before(ob0, a.z, b1, k1) ? 1u : 0u; }
-        if (a.x & 2u) { r0 += before(ob0 - 1, a.w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, a.w, b1, k1) ? 1u : 0u; }
+    for (uint32_t j0 = 0; j0 < maxc; j0 += 4) {
+        uint4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = *(const uint4 *)s_t[grp][(j0 + u) & (RD_BUCKET - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int ob0 = (int)a[u].y;
+            auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
+            if (a[u].x & 1u) { r0 += before(ob0, a[u].z, b0, k0) ? 1u : 0u; r1 += before(ob0, a[u].z, b1, k1) ? 1u : 0u; }
+            if (a[u].x & 2u) { r0 += before(ob0 - 1, a[u].w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, a[u].w, b1, k1) ? 1u : 0u; }
+        }
     }
     const int src0 = lane & 32;
     const uint64_t m0 = __ballot(kept0), m1 = __ballot(kept1);
@@ -1329,8 +1351,22 @@ __global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, 
     const int sup = gw / RD_ORD_RSSI_WAVES, wv = gw % RD_ORD_RSSI_WAVES;
     const int list0 = sup * RD_ORD_SUPER;
     if (list0 >= n_lists) return;
-    // records in front of this super-list, its lists' lengths, the overflow flag: independent loads, ONE wait (eight
-    // predicated loads per lane cover 512 lists; a loop with a run-time trip count waits for every load in turn)
+    // What the first task needs comes first: the lists' lengths, the overflow flag and - speculatively - entry wv of
+    // the super-list's first list (it IS the wave's first task whenever that list holds more than wv entries: a list
+    // averages 46, a super-list has 32 waves).  The totals of the lists in front (eight predicated loads per lane
+    // cover 512 lists) are only needed when the first record is stored: their loads are issued behind these and
+    // summed after the first task's samples have been asked for.
+    uint32_t nl[RD_ORD_SUPER];
+#pragma unroll
+    for (int k = 0; k < RD_ORD_SUPER; k++) nl[k] = list0 + k < n_lists ? wgtot[list0 + k] : 0u;
+    const uint32_t ovf = counters[RD_CNT_OVF];
+    const rd_otask t_spec = tasks[(size_t)list0 * RD_ORD_WG_TASKS + wv];
+    rd_k_h8 Ahi[3], Alo[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
+        Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
+    }
     uint32_t part = 0;
     for (int base = 0; base < list0; base += 512) {
         uint32_t v[8];
@@ -1342,38 +1378,15 @@ __global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, 
 #pragma unroll
         for (int k = 0; k < 8; k++) part += v[k];
     }
-    uint32_t nl[RD_ORD_SUPER];
-#pragma unroll
-    for (int k = 0; k < RD_ORD_SUPER; k++) nl[k] = list0 + k < n_lists ? wgtot[list0 + k] : 0u;
-    const uint32_t ovf = counters[RD_CNT_OVF];
     // the last super-list's first wave also leaves the run's totals for the host (records, matches)
     const bool totals = list0 + RD_ORD_SUPER >= n_lists && wv == 0;
     uint32_t mt = 0;
     if (totals)
         for (int i = lane; i < n_lists; i += 64) mt += wgtot[n_lists + i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(part);
     uint32_t n = 0;
 #pragma unroll
     for (int k = 0; k < RD_ORD_SUPER; k++) n += nl[k];
     n = __builtin_amdgcn_readfirstlane(n);
-    if (totals) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mt += (uint32_t)__shfl_xor((int)mt, o, 64);
-        if (lane == 0) {
-            counters[RD_CNT_TASKS] = first + n;
-            counters[RD_CNT_MATCH] = mt;
-            if (first + n > rec_cap) counters[RD_CNT_OVF] = ovf | 2u;
-        }
-    }
-    if (ovf || (uint32_t)wv >= n) return;  // (overflow: the host discards this run's records)
-    rd_k_h8 Ahi[3], Alo[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
-        Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
-    }
     // entry e of the super-list = entry e - (lengths of the lists before it) of one of its lists
     auto entry = [&](uint32_t e) -> const rd_otask * {
         uint32_t k = 0, pre = 0;
@@ -1393,10 +1406,29 @@ __global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, 
         return rd_rssi_prepare(view(__builtin_amdgcn_readfirstlane(t.stream)), __builtin_amdgcn_readfirstlane(t.call) * cfg.B, cfg,
                                __builtin_amdgcn_readfirstlane(t.q), lane);
     };
-    rd_otask t_cur = *entry((uint32_t)wv), t_nxt = *entry((uint32_t)wv + RD_ORD_RSSI_WAVES < n ? wv + RD_ORD_RSSI_WAVES : wv);
-    rd_rssi_job j_cur = job_of(t_cur);
+    const bool work = !ovf && (uint32_t)wv < n;  // (overflow: the host discards this run's records)
+    rd_otask t_cur = t_spec, t_nxt = t_spec;
+    rd_rssi_job j_cur = {};
     rd_rssi_data d_cur = {};
-    if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+    if (work) {
+        if ((uint32_t)wv >= __builtin_amdgcn_readfirstlane(nl[0])) t_cur = *entry((uint32_t)wv);
+        t_nxt = *entry((uint32_t)wv + RD_ORD_RSSI_WAVES < n ? wv + RD_ORD_RSSI_WAVES : wv);
+        j_cur = job_of(t_cur);
+        if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(part);
+    if (totals) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mt += (uint32_t)__shfl_xor((int)mt, o, 64);
+        if (lane == 0) {
+            counters[RD_CNT_TASKS] = first + n;
+            counters[RD_CNT_MATCH] = mt;
+            if (first + n > rec_cap) counters[RD_CNT_OVF] = ovf | 2u;
+        }
+    }
+    if (!work) return;
     for (uint32_t r = (uint32_t)wv; r < n; r += RD_ORD_RSSI_WAVES) {
         const rd_otask t_now = t_cur;
         const rd_rssi_job j_now = j_cur;

@@ -478,6 +478,45 @@ def test_multi_demodulator_lock_step(dsp, golden_streams):
         md.demodulate(raws[:2, : 2 * 8192])
 
 
+@pytest.mark.parametrize("B", [2048, 4096, 16384])
+def test_one_launch_block_at_other_block_sizes(dsp, B):
+    """The streaming handle's one-launch form (k_stream_block: Davis symbol / preamble / packet lengths, buffer_length
+    = 2 blocks, 2048 <= B <= 16384) at the ends and in the middle of that range: three receivers in lock step and a
+    single one, block by block against the C oracle (per-call lists with order, index, bytes; RSSI / SNR), then
+    reset() and the first blocks again (dsp.py:136-137, 139-246)."""
+    from oracle import c_oracle as CO
+    seeds = [3, 4, 11]
+    raws = synth.synth_streams(seeds)
+    nb = raws.shape[1] // (2 * B)
+    raws = np.ascontiguousarray(raws[:, : 2 * B * nb])
+    cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", B)
+    want, _ = CO.demod_batch(raws, CO.make_cfg(19200, 14, 16, 80, "1100101110001001", B), threads=2, cap_per_stream=256)
+    md = dsp.MultiDemodulator(cfg, len(seeds))
+    got = [[] for _ in seeds]
+    for b in range(nb):
+        out = md.demodulate(raws[:, 2 * B * b: 2 * B * (b + 1)])
+        for i, pk in enumerate(out):
+            got[i] += [(b, p.index, bytes(p.data).hex(), p.rssi, p.snr) for p in pk]
+    n = 0
+    for i in range(len(seeds)):
+        exp = [(p.call, p.index, bytes(p.data).hex(), p.rssi, p.snr) for p in want[i]]
+        assert [g[:3] for g in got[i]] == [e[:3] for e in exp], (B, i)
+        for g, e in zip(got[i], exp):
+            assert abs(g[3] - e[3]) < 1e-3 and abs(g[4] - e[4]) < 1e-3
+        n += len(exp)
+    assert n >= len(seeds)  # every stream holds its burst
+    dem = dsp.Demodulator(cfg)
+    single = []
+    for b in range(nb):
+        single += [(b, p.index, bytes(p.data).hex()) for p in dem.demodulate(raws[1, 2 * B * b: 2 * B * (b + 1)])]
+    assert single == [(p.call, p.index, bytes(p.data).hex()) for p in want[1]]
+    dem.reset()
+    again = []
+    for b in range(min(nb, 6)):
+        again += [(b, p.index, bytes(p.data).hex()) for p in dem.demodulate(raws[1, 2 * B * b: 2 * B * (b + 1)])]
+    assert again == [x for x in single if x[0] < min(nb, 6)]
+
+
 def test_submit_fetch_pipeline_equals_synchronous_path(dsp, golden_streams):
     """rd_demod_submit / rd_demod_fetch with two blocks in flight over a 33-block stream: the same
     packets (index, bytes, order, RSSI/SNR) as demodulate() block by block, and as the reference."""

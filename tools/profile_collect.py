@@ -10,41 +10,63 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-DEMOD_KERNEL_SOURCES = ("rd_demod_mfma.hip", "rd_mfma.h", "rd_internal.h", "rd_math.h")
+DEMOD_KERNEL_SYMBOL = b"_Z12k_demod_mfmaILi0ELi1ELi10EE"   # k_demod_mfma<0, 1, RD_MF_PRODUCT_OPT>: the product's variant
 
 
-def product_view(text: str) -> str:
-    """The source as the product library sees it: `#ifdef RD_DIAG` blocks (diagnostic variants, compiled only into
-    librtldavis_hip_diag.so) dropped, their `#else` branches kept."""
-    out, stack = [], []  # stack entries: [is_diag_block, in_else]
-    for line in text.splitlines():
-        t = line.strip()
-        if t.startswith("#if"):
-            stack.append([t.replace(" ", "") in ("#ifdefRD_DIAG", "#ifdefined(RD_DIAG)"), False])
-            if stack[-1][0]:
+def kernel_code_sha256(lib_path: str = None, symbol_prefix: bytes = DEMOD_KERNEL_SYMBOL) -> str:
+    """sha256 over the MACHINE CODE of the dominant kernel inside the built library - what bench.py checks a traffic
+    file against.  The library's clang offload bundles are walked, the gfx950 code object that defines the kernel is
+    parsed as ELF64 and the bytes of the function symbol are hashed: any change to the kernel changes the stamp,
+    changes elsewhere (tail kernels, host code, diagnostic variants, comments) do not.  '' when the library or the
+    symbol is missing."""
+    import struct
+    lib_path = lib_path or os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.so")
+    try:
+        with open(lib_path, "rb") as fh:
+            data = fh.read()
+    except OSError:
+        return ""
+    magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            return ""
+        pos = i + len(magic)
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        q = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            q += 24
+            triple = data[q:q + tl]
+            q += tl
+            if b"gfx950" not in triple or size == 0:
                 continue
-        elif t.startswith("#else") and stack and stack[-1][0]:
-            stack[-1][1] = True
-            continue
-        elif t.startswith("#endif") and stack:
-            if stack.pop()[0]:
+            elf = data[i + off:i + off + size]
+            if elf[:4] != b"\x7fELF":
                 continue
-        if any(d and not e for d, e in stack):
-            continue
-        out.append(line)
-    return "\n".join(out)
+            shoff, = struct.unpack_from("<Q", elf, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + k * shentsize) for k in range(shnum)]
+            for sec in secs:
+                if sec[1] != 2:  # SHT_SYMTAB
+                    continue
+                strtab = secs[sec[6]]
+                for k in range(sec[5] // 24):
+                    st_name, st_info, _o, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, sec[4] + 24 * k)
+                    if (st_info & 0xF) != 2 or st_shndx == 0 or st_shndx >= shnum:  # STT_FUNC, defined
+                        continue
+                    name_at = strtab[4] + st_name
+                    if elf[name_at:name_at + len(symbol_prefix)] != symbol_prefix:
+                        continue
+                    text = secs[st_shndx]
+                    start = text[4] + (st_value - text[3])
+                    return hashlib.sha256(elf[start:start + st_size]).hexdigest()
 
 
 def sources_sha256() -> str:
-    """Stamp of the sources of the dominant kernel, k_demod_mfma (what bench.py checks a traffic file against): the
-    kernel's own file and the headers it includes, as the product library is built from them (product_view).  The
-    tail kernels, the host code and the diagnostic variants may change without the demod kernel's HBM traffic changing."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "rtldavis_amd", "csrc")
-    for name in DEMOD_KERNEL_SOURCES:
-        with open(os.path.join(d, name), "r") as fh:
-            h.update(name.encode() + b"\0" + product_view(fh.read()).encode())
-    return h.hexdigest()
+    """The stamp bench.py checks a traffic file against (the name is historic: since round 3 it is the hash of the
+    demod kernel's machine code in the built product library, see kernel_code_sha256)."""
+    return kernel_code_sha256()
 
 
 def short(name: str) -> str:
@@ -123,7 +145,7 @@ def traffic(out_dir: str, commit: str) -> None:
     write_b = vals["WRITE_SIZE"] * 1024 if vals["WRITE_SIZE"] is not None else None
     alg = 4096 * 33 * 8192 * 2
     print(json.dumps({
-        "kernel": "k_demod_mfma", "commit": commit, "sources_sha256": sources_sha256(), "library_sha256": lib_sha,
+        "kernel": "k_demod_mfma", "commit": commit, "kernel_code_sha256": kernel_code_sha256(), "library_sha256": lib_sha,
         "workload": {"streams": 4096, "blocks": 33, "block_size": 8192},
         "FETCH_SIZE_KiB_per_dispatch": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_per_dispatch": vals["WRITE_SIZE"],
         "read_bytes": read_b, "write_bytes": write_b,
