@@ -134,3 +134,20 @@ def test_shard_ranges_cover_and_balance():
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         sizes = [hi - lo for lo, hi in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_traffic_stamp_finds_the_demod_kernel_in_the_built_library():
+    """bench.py accepts a profiles/rNN_traffic.json only when its stamp equals the hash of k_demod_mfma's machine code
+    in the library it loads (tools/profile_collect.py::kernel_code_sha256: offload bundle -> gfx950 ELF -> symbol)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("profile_collect", os.path.join(ROOT, "tools", "profile_collect.py"))
+    pc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pc)
+    stamp = pc.kernel_code_sha256()
+    assert len(stamp) == 64 and int(stamp, 16) >= 0
+    assert pc.kernel_code_sha256(symbol_prefix=b"_Z9no_such_kernel") == ""
+    assert pc.kernel_code_sha256(os.path.join(ROOT, "no_such_library.so")) == ""
+    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
+        tj = json.load(fh)
+    assert len(tj["kernel_code_sha256"]) == 64 and tj["traffic_bytes"] > tj["algorithmic_bytes"]
