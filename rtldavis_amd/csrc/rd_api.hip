@@ -293,6 +293,11 @@ struct rd_batch {
     size_t cnt_stride = RD_CNT_TOTAL;  // words per counter set (the per-stream match counters live behind the counters)
     // Pipelined completion (rd_batch_set_pipelined): the run's last kernel carries no event; the readback is hung on
     // the stop event of the NEXT demod kernel launched on the same stream (any handle's), see batch_adopt below.
+    // Self-fix: the demod kernel's waves re-evaluate the groups they flagged themselves (rd_demod_mfma.hip:
+    // rd_mf_selffix) and no k_fixup is launched; the search kernel clears the next counter set.  self_run: the run in
+    // flight was launched that way; self_redo: its (rare) overflow into the global list has been dealt with.
+    bool self_fix = false, self_run = false;
+    uint32_t self_pend_limit = 0;   // test hook RD_TEST_SELF_PEND: entries a wave keeps before the global list
     bool pipelined = false;
     bool deferred = false;          // the run in flight has no completion event yet (guarded by g_tail_mx)
     hipEvent_t kfirst = nullptr;    // stop event of this handle's demod launch when it adopts another run untimed
@@ -379,6 +384,18 @@ static int batch_alloc(rd_batch *b) {
         if (const char *e = getenv("RD_TEST_BUCKET_CAP")) {
             const long v = atol(e);
             if (v >= 1 && v < RD_BUCKET) b->bucket_limit = (uint32_t)v;
+        }
+    }
+    {   // RD_FIXUP_IMPL=self: self-fix - the demod kernel's waves re-evaluate the groups they flagged themselves and no
+        // k_fixup is launched (a step is 6-13 us shorter, the demod kernel 4-14 us longer: profiles/r03_self_fix.txt;
+        // off by default because the roofline fraction is quoted on that kernel).  RD_TEST_SELF_PEND makes a wave's own
+        // list short so that its overflow into the global list - k_fixup after the run, search and slice again -
+        // happens on ordinary inputs (test hook)
+        const char *fi = getenv("RD_FIXUP_IMPL");
+        b->self_fix = b->fast_ok && fi && fi[0] == 's';
+        if (const char *e = getenv("RD_TEST_SELF_PEND")) {
+            const long v = atol(e);
+            if (v >= 1 && v < 255) b->self_pend_limit = (uint32_t)v;
         }
     }
     b->cnt_stride = RD_CNT_TOTAL + (b->ord_ok ? (((size_t)b->n_streams + 3) & ~(size_t)3) : 0);
@@ -507,7 +524,7 @@ static int batch_adopt(hipStream_t st, hipEvent_t carrier) {
 }
 
 // search + slice part of a run (re-issued on list overflow: then with an event of its own, may_defer = false)
-static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = false) {
+static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = false, uint32_t *zero_next = nullptr) {
     const rd_layout lay = batch_layout(b);
     const long B = b->dc.B, L = b->dc.L;
     const bool last_on_slice = !b->parse;
@@ -521,12 +538,12 @@ static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = fals
         ob.scount = batch_cnt(b) + RD_CNT_TOTAL;
         b->ord_run = rd_launch_tail_ordered(lay, b->d_bits, b->bits_stride, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
                                             b->dc, b->n_blocks, ob, b->bucket_limit, b->d_recs, b->rec_cap, batch_cnt(b), st,
-                                            last_on_slice ? last : nullptr) != 0;
+                                            last_on_slice ? last : nullptr, zero_next, (uint32_t)b->cnt_stride) != 0;
         if (b->ord_run) b->dense = 1;  // one record per task from index 0 - and already in the final order
     }
     if (!b->ord_run) {
         rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
-                         b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
+                         b->dc, b->d_matches, b->match_cap, batch_cnt(b), st, nullptr, nullptr, zero_next, (uint32_t)b->cnt_stride);
         if (b->run_timing && b->run_detail) HIPCHK(hipEventRecord(b->ev[3], st));
         b->dense = rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1,
                                    b->n_blocks, 0, b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr,
@@ -588,22 +605,27 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     }
     // a pipelined run waiting on this stream is adopted by this run's demod kernel (its stop event)
     const bool adopt = batch_stream_has_tail(st);
+    const uint32_t dflags = b->self_fix ? RD_DEMOD_SELF_FIX : 0u;
+    uint32_t honoured = 0;
     if (b->timing && b->fast_ok) {
         // the demod kernel's dispatch carries its own start / stop events (no marker packets)
-        rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1]);
+        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit);
         if (adopt && (rc = batch_adopt(st, b->ev[1]))) return rc;
     } else if (b->fast_ok && adopt) {
-        rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst);
+        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit);
         if ((rc = batch_adopt(st, b->kfirst))) return rc;
     } else {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
-        if (b->fast_ok) rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st);
+        if (b->fast_ok) honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
         if (adopt && (rc = batch_adopt(st, b->ev[1] ))) return rc;
     }
-    rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
+    // self-fix: the demod kernel's waves have patched their own words; the search kernel clears the next counter set
+    b->self_run = b->fast_ok && (honoured & RD_DEMOD_SELF_FIX);
+    if (!b->self_run)
+        rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
-    rc = batch_search_slice(b, st, true);
+    rc = batch_search_slice(b, st, true, b->self_run ? cnt_next : nullptr);
     if (rc) return rc;
     b->ran = true;
     return RD_OK;
@@ -632,8 +654,17 @@ static int batch_finish(rd_batch *b) {
             HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
             b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
             redo_search = true;
+        } else if (b->self_run && b->h_cnt[RD_CNT_FIX] > 0) {
+            // self-fix run whose waves listed more words than they keep (quiet or degenerate input; RD_TEST_SELF_PEND):
+            // those went to the global list - k_fixup now, then search and slice again on the patched bits
+            const rd_layout lay = batch_layout(b);
+            rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 0, nullptr, st);
+            const uint32_t zero = 0;  // mark handled (k_fixup has read the count by the time this copy runs: same stream)
+            HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+            b->last_fix = (uint64_t)b->h_cnt[RD_CNT_FIX] + b->h_cnt[RD_CNT_SELF];
+            redo_search = true;
         } else if (attempt == 0) {
-            b->last_fix = b->h_cnt[RD_CNT_FIX];
+            b->last_fix = (uint64_t)b->h_cnt[RD_CNT_FIX] + (b->self_run ? b->h_cnt[RD_CNT_SELF] : 0u);
         }
         if (b->ord_run && b->h_cnt[RD_CNT_OVF]) {
             // a stream with more matches than its bucket holds (or more records than the list): this input goes
@@ -676,6 +707,9 @@ static int batch_finish(rd_batch *b) {
         }
         const uint32_t zero[4] = {0, 0, 0, 0};  // matches, boundary records, (unused), parsed
         HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
+        // (the ordered tail's per-stream match counts hold the first pass's matches: its search starts from zero again)
+        if (b->ord_ok && b->cnt_stride > RD_CNT_TOTAL)
+            HIPCHK(hipMemsetAsync(batch_cnt(b) + RD_CNT_TOTAL, 0, (b->cnt_stride - RD_CNT_TOTAL) * sizeof(uint32_t), st));
         int rc2 = batch_search_slice(b, st);
         if (rc2) return rc2;
     }

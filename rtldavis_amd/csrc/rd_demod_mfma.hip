@@ -44,7 +44,7 @@
 // predecessor exchange: three buffers of 64 x 16 B, then two carry slots (tile parity)
 // + the offset constant (four copies); a multiple of 32 so that XOR 16 toggles between the two carry slots
 #define RD_MF_XB_BYTES (3 * 1024 + 32 + 32)
-#define RD_MF_PEND 32
+#define RD_MF_PEND 64   // entries a wave keeps; with self-fix (below) it re-evaluates them itself at its end
 // tiles whose words are stored together (a multiple of 4 that divides the default chunk)
 #ifndef RD_MF_STAGE_TILES
 #define RD_MF_STAGE_TILES 4
@@ -467,6 +467,43 @@ __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count
 }
 
 // Store the staged words: four tiles as one 16-byte store per lane, fewer tile by tile.
+// Self-fix (RD_DEMOD_SELF_FIX, the batch path): a wave that has run out of tiles re-evaluates the groups it flagged
+// itself - the arithmetic of k_fixup (rd_exact_group_dw: float64 on integer data, exact), one lane per listed word -
+// and patches its own words.  A wave lists ~11 words in its life (the first group of each of its chunks, the first run
+// of a stream, the occasional group inside the guard band): one pass, ~1 % of the wave's instructions, instead of a
+// kernel launch whose 18 us are a launch and two dependent memory latencies.  The wave's word stores are waited for
+// first; the entries name words of the wave's own tiles only.  `noinline`: the float64 path's registers are needed
+// when the tile loop's are dead, and must not become part of the loop's allocation.
+__device__ __attribute__((noinline)) void rd_mf_selffix(uint32_t pend_addr, uint32_t count, rd_layout lay, uint32_t *self_counter) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const uint32_t lane = (uint32_t)rd_lane_now();
+    if (lane < count) {
+        const uint32_t e = rd_lds_read4(pend_addr + 4 * lane);
+        const uint32_t widx = e >> 4;
+        const uint32_t s = widx / (uint32_t)lay.bits_stride;
+        const uint32_t run = widx - s * (uint32_t)lay.bits_stride;
+        const uint8_t *base = lay.iq + (size_t)s * lay.stream_stride;
+        for (int g = 0; g < RD_GROUPS; g++) {
+            if (!((e >> g) & 1)) continue;
+            const long t0 = (long)run * RD_RUN + g * RD_GROUP;
+            const long left = (long)lay.n_samples - t0;
+            if (left <= 0) break;
+            const int cnt = left < RD_GROUP ? (int)left : RD_GROUP;
+            // samples t0-10 .. t0+9 = ten dwords at a 4-byte aligned address; those wholly outside the readable
+            // input are not touched (k_fixup's rule)
+            const uint8_t *p = base + 2 * (t0 - 10);
+            const long x = lay.valid_from - (t0 - 10), z = (long)lay.n_samples + 8 - (t0 - 10);
+            const int d_lo = x <= 0 ? 0 : x >= 20 ? 10 : (int)(x / 2);
+            const int d_hi = z <= 0 ? 0 : z >= 20 ? 10 : (int)((z + 1) / 2);
+            uint32_t dw[10];
+#pragma unroll
+            for (int d = 0; d < 10; d++) dw[d] = (d >= d_lo && d < d_hi) ? *(const uint32_t *)(p + 4 * d) : 0u;
+            ((uint8_t *)lay.bits)[(size_t)widx * 4 + g] = (uint8_t)rd_exact_group_dw(dw, t0, cnt, lay.valid_from);
+        }
+    }
+    if (lane == 0) atomicAdd(self_counter, count);
+}
+
 __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t nst, uint32_t *base, uint32_t stflags) {
     const int lane = rd_lane_now();
     if (nst == RD_MF_STAGE_TILES) {
@@ -614,6 +651,7 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 #define RD_OPT_HALO 2
 #define RD_OPT_STAMP 4
 #define RD_OPT_B8 8   // the 8-output formulation: 16 MFMAs per tile (rd_mf8_tile)
+#define RD_MF_STF_SELF 8192u   // stflags bit: self-fix (rd_mf_selffix); bits 16-23: entries a wave keeps (0 = RD_MF_PEND)
 #define RD_OPT_FPROBE 16  // diagnostic library: what an in-tile preamble test would cost (rd_mf_search_probe)
 #define RD_STAMP_WORDS 12
 template <int DBG, int NBUF, int OPT>
@@ -674,6 +712,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     // lane 63 of the previous tile.  Buffers: X0 at 0, X1 and X3 at 1024, X2 at 2048 (X1 is dead when X3 is
     // written), two carry slots at 3072 (lane 63's X3, alternating with the tile parity).
     const uint32_t xb_addr = rd_lds_addr(xb), pend_addr = rd_lds_addr(mypend);
+    const uint32_t pend_limit = ((stflags >> 16) & 0xFFu) && ((stflags >> 16) & 0xFFu) < RD_MF_PEND ? ((stflags >> 16) & 0xFFu) : RD_MF_PEND;
     const uint32_t stage_addr = rd_lds_addr(s_stage[wave]);
     const uint32_t xw = xb_addr + 16 * lane;                       // + 0 / 1024 / 2048 for b = 0 / 1 / 2
     uint32_t xw3 = xb_addr + (lane == 63 ? 3072 : 1024 + 16 * lane);
@@ -937,7 +976,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         const uint64_t fm = (any_flag || !carry) ? __ballot(gmask != 0) : 0;
         if (fm) {
             const uint32_t nf = (uint32_t)__popcll(fm);
-            if (npend + nf > RD_MF_PEND) {
+            if (npend + nf > pend_limit) {  // (with self-fix: the rare overflow goes to the global list, k_fixup then runs)
                 rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
                 npend = 0;
             }
@@ -952,7 +991,12 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         if (NBUF == 2) buf ^= 1;
     }
     if (nst) rd_mf_store_staged(stage_addr, nst, st_base, stflags);
-    if (npend) rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
+    if (npend) {
+        if (stflags & RD_MF_STF_SELF)
+            rd_mf_selffix(pend_addr, npend, lay, counters + RD_CNT_QUEUE0 + (wave_id % RD_NQUEUE) * RD_QUEUE_STRIDE + RD_SELF_WORD);
+        else
+            rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
+    }
     if (STAMP && dbg_g) {  // a buffer of its own: nothing else in the kernel reads it
         const uint64_t t1 = rd_stamp(), r1 = rd_stamp_real();
         sm_comp += t1 - sm_mark;
@@ -1033,6 +1077,7 @@ struct rd_mf_launch_args {
     uint32_t *fix_list, fix_cap, *counters;
     hipStream_t st;
     hipEvent_t ev_start, ev_stop;
+    uint32_t stf_extra = 0;  // RD_MF_STF_SELF and the pending limit, or-ed into the kernel's stflags
     float *dbg_g;
 };
 
@@ -1077,15 +1122,16 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
 #endif
     if (a.ev_start || a.ev_stop)
         hipExtLaunchKernelGGL((k_demod_mfma<D, NB, OPT>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.ev_start,
-                              a.ev_stop, 0, a.lay, a.tps, a.total, chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags);
+                              a.ev_stop, 0, a.lay, a.tps, a.total, chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags | a.stf_extra);
     else
         hipLaunchKernelGGL((k_demod_mfma<D, NB, OPT>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.lay, a.tps, a.total,
-                           chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags);
+                           chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags | a.stf_extra);
 }
 
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g) {
+                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t pend_limit) {
     rd_mf_launch_args a;
+    a.stf_extra = ((flags & RD_DEMOD_SELF_FIX) ? RD_MF_STF_SELF : 0u) | ((pend_limit & 0xFFu) << 16);
     a.lay = lay;
     a.tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     a.total64 = (uint64_t)lay.n_streams * a.tps;

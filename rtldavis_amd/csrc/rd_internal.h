@@ -10,7 +10,13 @@
 // block-boundary positions; PARSED: CRC-valid messages
 // OVF: the ordered tail could not hold this input (bit 0: a stream with more than RD_BUCKET matches, bit 1: more
 // records than the list has room for)
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_OVF = 5, RD_CNT_SLOTS = 8 };
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_OVF = 5, RD_CNT_SELF = 6, RD_CNT_SLOTS = 8 };
+// RD_CNT_FIX: entries in the global fix-up list (k_fixup's input).  RD_CNT_SELF: groups' words the demod kernel
+// re-evaluated itself (self-fix, below); its per-wave contributions are added to word RD_SELF_WORD of the wave's
+// work-queue slot (32 cache lines instead of one) and summed into RD_CNT_SELF by the search kernel's first wave.
+#define RD_SELF_WORD 1
+// rd_launch_demod flags
+#define RD_DEMOD_SELF_FIX 1u   /* a wave re-evaluates the groups it flagged itself when it has run out of tiles: no k_fixup launch */
 // Behind the RD_CNT_SLOTS counters the host reads back: the demod kernel's work queues (chunks handed out beyond
 // the first one of every wave).  One counter word sustains ~90 atomics per microsecond, so there are RD_NQUEUE of
 // them, 256 bytes apart; wave w draws from queue w % RD_NQUEUE, which owns the chunks nwaves + q + RD_NQUEUE k.
@@ -53,12 +59,15 @@ int rd_ensure_device_public(void);
 
 // --- launches (all asynchronous on `st`) ---
 // ev_start / ev_stop (optional): events that receive the kernel's own begin / end timestamps.
-void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// flags: RD_DEMOD_SELF_FIX; pend_limit (test hook, 0 = the kernel's own): entries a wave keeps before it falls back to the
+// global list.  Returns the flags the launched kernel honours (the round-1 VALU kernel of the diagnostic library: none).
+uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t flags = 0, uint32_t pend_limit = 0);
 // The same stage with the FIR on the matrix pipe (rd_demod_mfma.hip); rd_launch_demod dispatches to it
 // unless RD_K1_IMPL=valu.  dbg_g (test hook): when given, the kernel also dumps g[tile][2048][2].
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr);
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr,
+                          uint32_t flags = 0, uint32_t pend_limit = 0);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
@@ -72,7 +81,10 @@ void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fi
 // smatch / scount (both or neither): the matches go to per-stream buckets instead of the one list (ordered tail)
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
-                      hipStream_t st, int32_t *smatch = nullptr, uint32_t *scount = nullptr);
+                      hipStream_t st, int32_t *smatch = nullptr, uint32_t *scount = nullptr,
+                      uint32_t *zero_next = nullptr, uint32_t zero_words = 0);
+// zero_next / zero_words (self-fix runs, which launch no k_fixup): the search kernel's first workgroup clears the
+// handle's next counter set and sums the demod waves' self-fix counts into RD_CNT_SELF
 // The ordered tail of the batch path (rd_kernels.hip): search into per-stream buckets, per-stream rank and dedupe,
 // RSSI / SNR, records written in the reference's order.  RD_BUCKET matches per stream at most.
 #define RD_BUCKET 32
@@ -87,7 +99,8 @@ struct rd_ord_bufs {
 };
 int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
                            const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
-                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop = nullptr);
+                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop = nullptr,
+                           uint32_t *zero_next = nullptr, uint32_t zero_words = 0);
 // Slice + RSSI/SNR, one wave per match.  batch_mode = 1: position = absolute sample, calls derived
 // from it (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
 // lay.iq points at the newest block's first sample.

@@ -228,12 +228,12 @@ static const rd_k_params &rd_k_get_params() {
     return p;
 }
 
-void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                     hipEvent_t ev_start, hipEvent_t ev_stop) {
+uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                         hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t flags, uint32_t pend_limit) {
     const rd_k_params &P = rd_k_get_params();
     if (P.impl_mfma) {
-        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop);
-        return;
+        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, pend_limit);
+        return flags & RD_DEMOD_SELF_FIX;
     }
     const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
@@ -242,7 +242,7 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
     // persistent grid: workgroups per CU (72 VGPRs and 18.5 KiB LDS admit 7); RD_K1_WGS_PER_CU overrides
     const uint64_t max_wgs = 256ull * P.per_cu_valu;
     if (wgs > max_wgs) wgs = max_wgs;
-    if (wgs == 0) return;
+    if (wgs == 0) return 0;
     // With events given, the dispatch itself carries them (hipExtLaunchKernelGGL): its begin / end
     // timestamps, without the marker packets of hipEventRecord that idle the GPU for ~6 us each.
 #define RD_LAUNCH_K1(D, N)                                                                                          \
@@ -255,17 +255,18 @@ void rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap,
                                fix_list, fix_cap, counters);                                                        \
     } while (0)
 #ifdef RD_DIAG
-    if (P.dbg == 1) { RD_LAUNCH_K1(1, RD_NPK_DEFAULT); return; }
-    if (P.dbg == 2) { RD_LAUNCH_K1(2, RD_NPK_DEFAULT); return; }
-    if (P.npk == 0) { RD_LAUNCH_K1(0, 0); return; }
-    if (P.npk == 2) { RD_LAUNCH_K1(0, 2); return; }
-    if (P.npk == 4) { RD_LAUNCH_K1(0, 4); return; }
-    if (P.npk == 6) { RD_LAUNCH_K1(0, 6); return; }
-    if (P.npk == 7) { RD_LAUNCH_K1(0, 7); return; }
-    if (P.npk == 9) { RD_LAUNCH_K1(0, 9); return; }
+    if (P.dbg == 1) { RD_LAUNCH_K1(1, RD_NPK_DEFAULT); return 0; }
+    if (P.dbg == 2) { RD_LAUNCH_K1(2, RD_NPK_DEFAULT); return 0; }
+    if (P.npk == 0) { RD_LAUNCH_K1(0, 0); return 0; }
+    if (P.npk == 2) { RD_LAUNCH_K1(0, 2); return 0; }
+    if (P.npk == 4) { RD_LAUNCH_K1(0, 4); return 0; }
+    if (P.npk == 6) { RD_LAUNCH_K1(0, 6); return 0; }
+    if (P.npk == 7) { RD_LAUNCH_K1(0, 7); return 0; }
+    if (P.npk == 9) { RD_LAUNCH_K1(0, 9); return 0; }
 #endif
     RD_LAUNCH_K1(0, RD_NPK_DEFAULT);
 #undef RD_LAUNCH_K1
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -402,9 +403,22 @@ template <int S_, int P_, uint64_t PRE_, bool BKT = false>
 __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
                                                 long base, long groups_per_stream, long p_lo, long p_hi,
                                                 rd_devcfg cfg, rd_match *matches, uint32_t match_cap,
-                                                uint32_t *counters, int32_t *smatch = nullptr, uint32_t *scount = nullptr) {
+                                                uint32_t *counters, int32_t *smatch = nullptr, uint32_t *scount = nullptr,
+                                                uint32_t *zero_next = nullptr, uint32_t zero_words = 0) {
     __shared__ rd_match pend_all[RD_SEARCH_WAVES][RD_MATCH_PEND];
     const int lane = threadIdx.x & 63;
+    // With the demod kernel's self-fix there is no k_fixup launch in front of this kernel; its two side jobs are done
+    // here by the first workgroup: the counter set of the handle's NEXT run is cleared, and the per-queue counts of the
+    // words the demod kernel's waves re-evaluated themselves are summed for the host.
+    if (zero_next && blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x) zero_next[i] = 0;
+        if (threadIdx.x < 64) {
+            uint32_t v = lane < RD_NQUEUE ? counters[RD_CNT_QUEUE0 + lane * RD_QUEUE_STRIDE + RD_SELF_WORD] : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+            if (lane == 0) counters[RD_CNT_SELF] = v;
+        }
+    }
     rd_match *pend = pend_all[threadIdx.x >> 6];
     uint32_t npend = 0;  // wave-uniform
     // a wave covers 64 consecutive lane-groups (128 positions each) of ONE stream, so the
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
 
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
-                      hipStream_t st, int32_t *smatch, uint32_t *scount) {
+                      hipStream_t st, int32_t *smatch, uint32_t *scount, uint32_t *zero_next, uint32_t zero_words) {
     if (p_hi < p_lo || n_streams == 0) return;
     const long base = (p_lo >> 5) << 5;  // floor to a word boundary (p_lo may be negative)
     const long nwords = (n_bits + 31) / 32;
@@ -615,13 +629,16 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
     // (bit m of the mask = symbol m -> 0x91D3)
     if (smatch && scount && cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
         hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull, true>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
-                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, smatch, scount);
+                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, smatch, scount,
+                           zero_next, zero_words);
     else if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
         hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
-                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
+                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, nullptr, nullptr,
+                           zero_next, zero_words);
     else
         hipLaunchKernelGGL((k_search<0, 0, 0>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride, n_streams,
-                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
+                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, nullptr, nullptr, zero_next,
+                           zero_words);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1465,11 +1482,13 @@ __global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, 
 // shape is not the one it is built for (the caller then uses rd_launch_search + rd_launch_slice)
 int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
                            const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
-                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop) {
+                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop, uint32_t *zero_next,
+                           uint32_t zero_words) {
     if (!(cfg.S == 14 && cfg.P == 16 && cfg.K == 80 && cfg.pre_mask == 0x91D3ull) || n_bits >= (1l << 30) || cfg.B >= (1 << 24) ||
         !ob.smatch || lay.n_streams <= 0)
         return 0;
-    rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount);
+    rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount,
+                     zero_next, zero_words);
     const uint32_t cg = (uint32_t)(lay.n_streams + RD_ORD_WG_STREAMS - 1) / RD_ORD_WG_STREAMS;
     hipLaunchKernelGGL((k_classify_ord<14, 80>), dim3(cg), dim3(32 * RD_ORD_WG_STREAMS), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32), cfg,
                        ob.smatch, ob.scount, lay.n_streams, bucket_limit < RD_BUCKET ? bucket_limit : (uint32_t)RD_BUCKET, n_calls,

@@ -944,6 +944,29 @@ def test_pipelined_completion_returns_the_same_packets(dsp, batchmod, golden_str
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"RD_FIXUP_IMPL": "self"}, {"RD_FIXUP_IMPL": "self", "RD_TEST_SELF_PEND": "2"},
+                                 {"RD_FIXUP_IMPL": "self", "RD_TEST_SELF_PEND": "2", "RD_TAIL_IMPL": "legacy"}])
+def test_self_fix_forms_agree_with_the_fixtures(dsp, batchmod, golden_streams, monkeypatch, env):
+    """RD_FIXUP_IMPL=self: a wave of the demod kernel re-evaluates the groups it flagged itself (rd_mf_selffix: k_fixup's
+    exact arithmetic, dsp.py:71-98 in float64 on integer data) and no k_fixup is launched; the search kernel clears
+    the next run's counters.  RD_TEST_SELF_PEND=2 lets a wave keep two entries only, so that most of them overflow
+    into the global list and the host runs k_fixup after the run, then search and slice again (ordered and unordered
+    tail).  Bits and packets of every form = the fixtures, twice in a row (the default form, k_fixup, is what every
+    other test runs)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    seeds = list(range(12))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    for _ in range(2):
+        res = bd.demodulate(raw)
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+            assert sha(bd.bits(i)) == golden_streams[str(seed)]["bits_sha256"], (env, seed)
+    assert bd.counters()["fixup_runs"] >= len(seeds)   # at least the first run of every stream
+
+
+@pytest.mark.gpu
 def test_ordered_tail_falls_back_when_a_stream_overflows_its_bucket(dsp, batchmod, golden_streams, monkeypatch):
     """RD_TEST_BUCKET_CAP=2: every stream has more than two matches, the ordered tail raises its overflow flag, and
     rd_batch_results re-runs the unordered kernels on the same bits - the fixtures' packets, twice in a row (the
