@@ -421,21 +421,23 @@ def main():
                              f"{'ok' if ok else 'MISMATCH'}) - result invalid")
 
     # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 runs
-    # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel's MACHINE CODE in
-    # the library it was measured on (tools/profile_collect.py::kernel_code_sha256); valid for the default workload
+    # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel's INSTRUCTIONS as
+    # compiled for the library it was measured on (tools/profile_collect.py::isa_sha256; the build leaves the tree's
+    # stamp next to the library); valid for the default workload
     # only.  A file that belongs to another build of the kernel is refused.
     traffic, traffic_note = None, None
     try:
         import glob
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import profile_collect
-        stamp = profile_collect.kernel_code_sha256(_lib.LIB_PATH)   # the demod kernel's machine code in the library in use
+        # the stamp the build left next to the product library (only that library has one)
+        stamp = profile_collect.kernel_isa_stamp() if os.path.samefile(_lib.LIB_PATH, os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.so")) else ""
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True)
         for path in files:  # the newest round's file that was measured on this very kernel code
             with open(path) as fh:
                 tj = json.load(fh)
             w = tj["workload"]
-            if not stamp or tj.get("kernel_code_sha256") != stamp:
+            if not stamp or tj.get("kernel_isa_sha256") != stamp:
                 if traffic_note is None:
                     traffic_note = (f"profiles/{os.path.basename(path)} was measured on another build of k_demod_mfma "
                                     f"(commit {tj.get('commit')}): not used; regenerate with tools/profile_round.sh")

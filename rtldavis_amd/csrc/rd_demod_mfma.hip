@@ -44,7 +44,8 @@
 // predecessor exchange: three buffers of 64 x 16 B, then two carry slots (tile parity)
 // + the offset constant (four copies); a multiple of 32 so that XOR 16 toggles between the two carry slots
 #define RD_MF_XB_BYTES (3 * 1024 + 32 + 32)
-#define RD_MF_PEND 64   // entries a wave keeps; with self-fix (below) it re-evaluates them itself at its end
+#define RD_MF_PEND 32        // entries a wave keeps before it appends them to the global list
+#define RD_MF_PEND_SELF 64   // ... in the self-fix variant (RD_OPT_SELF), which re-evaluates them itself at its end
 // tiles whose words are stored together (a multiple of 4 that divides the default chunk)
 #ifndef RD_MF_STAGE_TILES
 #define RD_MF_STAGE_TILES 4
@@ -651,7 +652,9 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 #define RD_OPT_HALO 2
 #define RD_OPT_STAMP 4
 #define RD_OPT_B8 8   // the 8-output formulation: 16 MFMAs per tile (rd_mf8_tile)
-#define RD_MF_STF_SELF 8192u   // stflags bit: self-fix (rd_mf_selffix); bits 16-23: entries a wave keeps (0 = RD_MF_PEND)
+// stflags bits 16-23 (self-fix variant, test hook): entries a wave keeps before the global list (0 = RD_MF_PEND_SELF)
+#define RD_OPT_SELF 32    // self-fix variant (rd_mf_selffix): launched for RD_DEMOD_SELF_FIX, a kernel of its own so that
+                          // the default kernel carries neither the call nor its scratch
 #define RD_OPT_FPROBE 16  // diagnostic library: what an in-tile preamble test would cost (rd_mf_search_probe)
 #define RD_STAMP_WORDS 12
 template <int DBG, int NBUF, int OPT>
@@ -663,7 +666,8 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     // (0.54 vs 0.53 ms: the fourth wave per SIMD is worth more than the second tile in flight).
     __shared__ __attribute__((aligned(16))) uint8_t s_img[RD_MF_WAVES][NBUF][RD_MF_IMG_PAD];
     __shared__ __attribute__((aligned(32))) uint8_t s_xb[RD_MF_WAVES][RD_MF_XB_BYTES];
-    __shared__ uint32_t s_pend[RD_MF_WAVES][RD_MF_PEND];
+    constexpr uint32_t PEND = (OPT & RD_OPT_SELF) ? RD_MF_PEND_SELF : RD_MF_PEND;
+    __shared__ uint32_t s_pend[RD_MF_WAVES][PEND];
     // packed words of up to four consecutive tiles of a stream, stored together: one 16-byte store per lane
     // (1 KiB contiguous per wave) instead of four dword stores (round 1: a dword store per tile cost 20 % of
     // the read bandwidth, profiles/r01_ubench_read_bw.txt)
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     // lane 63 of the previous tile.  Buffers: X0 at 0, X1 and X3 at 1024, X2 at 2048 (X1 is dead when X3 is
     // written), two carry slots at 3072 (lane 63's X3, alternating with the tile parity).
     const uint32_t xb_addr = rd_lds_addr(xb), pend_addr = rd_lds_addr(mypend);
-    const uint32_t pend_limit = ((stflags >> 16) & 0xFFu) && ((stflags >> 16) & 0xFFu) < RD_MF_PEND ? ((stflags >> 16) & 0xFFu) : RD_MF_PEND;
+    const uint32_t pend_limit = (OPT & RD_OPT_SELF) && ((stflags >> 16) & 0xFFu) && ((stflags >> 16) & 0xFFu) < PEND ? ((stflags >> 16) & 0xFFu) : PEND;
     const uint32_t stage_addr = rd_lds_addr(s_stage[wave]);
     const uint32_t xw = xb_addr + 16 * lane;                       // + 0 / 1024 / 2048 for b = 0 / 1 / 2
     uint32_t xw3 = xb_addr + (lane == 63 ? 3072 : 1024 + 16 * lane);
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     }
     if (nst) rd_mf_store_staged(stage_addr, nst, st_base, stflags);
     if (npend) {
-        if (stflags & RD_MF_STF_SELF)
+        if constexpr ((OPT & RD_OPT_SELF) != 0)
             rd_mf_selffix(pend_addr, npend, lay, counters + RD_CNT_QUEUE0 + (wave_id % RD_NQUEUE) * RD_QUEUE_STRIDE + RD_SELF_WORD);
         else
             rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
@@ -1077,7 +1081,8 @@ struct rd_mf_launch_args {
     uint32_t *fix_list, fix_cap, *counters;
     hipStream_t st;
     hipEvent_t ev_start, ev_stop;
-    uint32_t stf_extra = 0;  // RD_MF_STF_SELF and the pending limit, or-ed into the kernel's stflags
+    uint32_t stf_extra = 0;  // the self-fix variant's pending limit, or-ed into the kernel's stflags
+    bool self_fix = false;
     float *dbg_g;
 };
 
@@ -1131,7 +1136,8 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                           hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t pend_limit) {
     rd_mf_launch_args a;
-    a.stf_extra = ((flags & RD_DEMOD_SELF_FIX) ? RD_MF_STF_SELF : 0u) | ((pend_limit & 0xFFu) << 16);
+    a.self_fix = (flags & RD_DEMOD_SELF_FIX) != 0;
+    a.stf_extra = a.self_fix ? ((pend_limit & 0xFFu) << 16) : 0u;
     a.lay = lay;
     a.tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     a.total64 = (uint64_t)lay.n_streams * a.tps;
@@ -1151,7 +1157,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     }
 #ifdef RD_DIAG
     const rd_mf_params &P = rd_mf_get_params();
-    const int key = P.dbg * 1000 + P.nbuf * 100 + P.opt;  // (opt < 100)
+    const int key = P.dbg * 1000 + P.nbuf * 100 + (P.opt | (a.self_fix ? RD_OPT_SELF : 0));  // (opt < 100)
     switch (key) {
 #define RD_V(D, NB, O) case (D) * 1000 + (NB) * 100 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
         RD_V(0, 1, 0) RD_V(0, 1, 1) RD_V(0, 1, 2) RD_V(0, 1, 3) RD_V(0, 1, 4) RD_V(0, 1, 5) RD_V(0, 1, 6) RD_V(0, 1, 7)
@@ -1161,7 +1167,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
         RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
         RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
         RD_V(10, 1, 0) RD_V(10, 1, 4) RD_V(11, 1, 0) RD_V(11, 1, 4)
-        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10) RD_V(0, 1, 26) RD_V(1, 1, 10) RD_V(2, 1, 10) RD_V(6, 1, 10)
+        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10) RD_V(0, 1, 26) RD_V(1, 1, 10) RD_V(2, 1, 10) RD_V(6, 1, 10) RD_V(0, 1, 42)
         RD_V(0, 2, 0)
 #undef RD_V
         default:
@@ -1169,7 +1175,8 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
             abort();
     }
 #else
-    rd_mf_launch_variant<0, 1, RD_MF_PRODUCT_OPT>(a);
+    if (a.self_fix) rd_mf_launch_variant<0, 1, (RD_MF_PRODUCT_OPT | RD_OPT_SELF)>(a);
+    else rd_mf_launch_variant<0, 1, RD_MF_PRODUCT_OPT>(a);
 #endif
 }
 

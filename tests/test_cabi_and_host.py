@@ -136,18 +136,23 @@ def test_shard_ranges_cover_and_balance():
         assert max(sizes) - min(sizes) <= 1
 
 
-def test_traffic_stamp_finds_the_demod_kernel_in_the_built_library():
-    """bench.py accepts a profiles/rNN_traffic.json only when its stamp equals the hash of k_demod_mfma's machine code
-    in the library it loads (tools/profile_collect.py::kernel_code_sha256: offload bundle -> gfx950 ELF -> symbol)."""
+def test_traffic_stamp_of_the_built_demod_kernel():
+    """bench.py accepts a profiles/rNN_traffic.json only when its stamp equals the one the build left next to the
+    library: a sha256 over the instructions of k_demod_mfma (tools/profile_collect.py::isa_sha256 - the kernel's body
+    in hipcc's device assembly, comments and label numbers dropped)."""
     import importlib.util
     import json
     spec = importlib.util.spec_from_file_location("profile_collect", os.path.join(ROOT, "tools", "profile_collect.py"))
     pc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(pc)
-    stamp = pc.kernel_code_sha256()
-    assert len(stamp) == 64 and int(stamp, 16) >= 0
-    assert pc.kernel_code_sha256(symbol_prefix=b"_Z9no_such_kernel") == ""
-    assert pc.kernel_code_sha256(os.path.join(ROOT, "no_such_library.so")) == ""
+    stamp = pc.kernel_isa_stamp()
+    assert len(stamp) == 64 and int(stamp, 16) >= 0, "make -C rtldavis_amd/csrc all writes librtldavis_hip.stamp"
+    asm = "\n".join(["_Z5otherv:", "\ts_endpgm", pc.DEMOD_KERNEL_SYMBOL + "v9rd_layout: ; @k", "; %bb.0:", "\ts_load_dword s0, s[4:5], 0x0 ; c",
+                     ".LBB7_2:", "\ts_cbranch_scc1 .LBB7_2", "\ts_endpgm", "\t.section x"])
+    again = asm.replace("LBB7_", "LBB3_").replace("; c", "; another comment")
+    assert pc.isa_sha256(asm) == pc.isa_sha256(again) != ""
+    assert pc.isa_sha256(asm.replace("0x0", "0x4")) != pc.isa_sha256(asm)
+    assert pc.isa_sha256("_Z5otherv:\n\ts_endpgm\n") == ""
     with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
         tj = json.load(fh)
-    assert len(tj["kernel_code_sha256"]) == 64 and tj["traffic_bytes"] > tj["algorithmic_bytes"]
+    assert len(tj["kernel_isa_sha256"]) == 64 and tj["traffic_bytes"] > tj["algorithmic_bytes"]

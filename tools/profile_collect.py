@@ -10,63 +10,41 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-DEMOD_KERNEL_SYMBOL = b"_Z12k_demod_mfmaILi0ELi1ELi10EE"   # k_demod_mfma<0, 1, RD_MF_PRODUCT_OPT>: the product's variant
+DEMOD_KERNEL_SYMBOL = "_Z12k_demod_mfmaILi0ELi1ELi10EE"   # k_demod_mfma<0, 1, RD_MF_PRODUCT_OPT>: the default variant
+STAMP_FILE = os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.stamp")
 
 
-def kernel_code_sha256(lib_path: str = None, symbol_prefix: bytes = DEMOD_KERNEL_SYMBOL) -> str:
-    """sha256 over the MACHINE CODE of the dominant kernel inside the built library - what bench.py checks a traffic
-    file against.  The library's clang offload bundles are walked, the gfx950 code object that defines the kernel is
-    parsed as ELF64 and the bytes of the function symbol are hashed: any change to the kernel changes the stamp,
-    changes elsewhere (tail kernels, host code, diagnostic variants, comments) do not.  '' when the library or the
-    symbol is missing."""
-    import struct
-    lib_path = lib_path or os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.so")
+def isa_sha256(asm_text: str, symbol_prefix: str = DEMOD_KERNEL_SYMBOL) -> str:
+    """sha256 over the INSTRUCTIONS of the dominant kernel, from the device assembly hipcc writes for
+    rd_demod_mfma.hip (-S --cuda-device-only, the product's flags): the kernel's body from its label to s_endpgm,
+    comments and local labels dropped, basic-block label numbers normalised (they count the functions in front of the
+    kernel).  Any change to the kernel's code changes it; other kernels, host code, diagnostic variants and comments
+    do not.  (The bytes inside the .so are no use for this: their pc-relative literals move with every function added
+    to the file.)  '' when the kernel is not in the text."""
+    import re
+    body, inside = [], False
+    for line in asm_text.splitlines():
+        if not inside:
+            if line.startswith(symbol_prefix) and line.rstrip().split(";")[0].rstrip().endswith(":"):
+                inside = True
+            continue
+        t = line.split(";")[0].strip()
+        if not t or t.startswith(".L") or t.startswith("."):
+            continue
+        body.append(re.sub(r"LBB\d+_", "LBB_", t))
+        if t == "s_endpgm":
+            return hashlib.sha256("\n".join(body).encode()).hexdigest()
+    return ""
+
+
+def kernel_isa_stamp() -> str:
+    """The stamp the build left next to the product library (rtldavis_amd/csrc/Makefile: librtldavis_hip.stamp =
+    isa_sha256 of the demod kernel as compiled for that library); '' when there is none."""
     try:
-        with open(lib_path, "rb") as fh:
-            data = fh.read()
+        with open(STAMP_FILE) as fh:
+            return fh.read().strip()
     except OSError:
         return ""
-    magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
-    while True:
-        i = data.find(magic, pos)
-        if i < 0:
-            return ""
-        pos = i + len(magic)
-        n = struct.unpack_from("<Q", data, i + 24)[0]
-        q = i + 32
-        for _ in range(n):
-            off, size, tl = struct.unpack_from("<QQQ", data, q)
-            q += 24
-            triple = data[q:q + tl]
-            q += tl
-            if b"gfx950" not in triple or size == 0:
-                continue
-            elf = data[i + off:i + off + size]
-            if elf[:4] != b"\x7fELF":
-                continue
-            shoff, = struct.unpack_from("<Q", elf, 0x28)
-            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
-            secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + k * shentsize) for k in range(shnum)]
-            for sec in secs:
-                if sec[1] != 2:  # SHT_SYMTAB
-                    continue
-                strtab = secs[sec[6]]
-                for k in range(sec[5] // 24):
-                    st_name, st_info, _o, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, sec[4] + 24 * k)
-                    if (st_info & 0xF) != 2 or st_shndx == 0 or st_shndx >= shnum:  # STT_FUNC, defined
-                        continue
-                    name_at = strtab[4] + st_name
-                    if elf[name_at:name_at + len(symbol_prefix)] != symbol_prefix:
-                        continue
-                    text = secs[st_shndx]
-                    start = text[4] + (st_value - text[3])
-                    return hashlib.sha256(elf[start:start + st_size]).hexdigest()
-
-
-def sources_sha256() -> str:
-    """The stamp bench.py checks a traffic file against (the name is historic: since round 3 it is the hash of the
-    demod kernel's machine code in the built product library, see kernel_code_sha256)."""
-    return kernel_code_sha256()
 
 
 def short(name: str) -> str:
@@ -145,7 +123,7 @@ def traffic(out_dir: str, commit: str) -> None:
     write_b = vals["WRITE_SIZE"] * 1024 if vals["WRITE_SIZE"] is not None else None
     alg = 4096 * 33 * 8192 * 2
     print(json.dumps({
-        "kernel": "k_demod_mfma", "commit": commit, "kernel_code_sha256": kernel_code_sha256(), "library_sha256": lib_sha,
+        "kernel": "k_demod_mfma", "commit": commit, "kernel_isa_sha256": kernel_isa_stamp(), "library_sha256": lib_sha,
         "workload": {"streams": 4096, "blocks": 33, "block_size": 8192},
         "FETCH_SIZE_KiB_per_dispatch": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_per_dispatch": vals["WRITE_SIZE"],
         "read_bytes": read_b, "write_bytes": write_b,
@@ -165,5 +143,11 @@ if __name__ == "__main__":
         pmc(sys.argv[2])
     elif cmd == "traffic":
         traffic(sys.argv[2], sys.argv[3])
+    elif cmd == "isa-stamp":   # isa-stamp <device assembly of rd_demod_mfma.hip>
+        with open(sys.argv[2]) as fh:
+            st = isa_sha256(fh.read())
+        if not st:
+            sys.exit("k_demod_mfma not found in " + sys.argv[2])
+        print(st)
     elif cmd == "stamp":
-        print(sources_sha256())
+        print(kernel_isa_stamp())
