@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--self-fix", action="store_true",
                     help="RD_FIXUP_IMPL=self: the demod kernel re-evaluates its flagged groups itself, no k_fixup launch "
                          "(a shorter step, a longer demod kernel: profiles/r03_self_fix.txt)")
+    ap.add_argument("--fused-search", action="store_true",
+                    help="RD_SEARCH_IMPL=fused: the preamble test inside the demod kernel (profiles/r03_fused_search.txt)")
     ap.add_argument("--stage-times", action="store_true", help="time every kernel stage (adds events)")
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "
@@ -285,6 +287,8 @@ def main():
     host = np.tile(uniq, (reps, 1))[:n_streams]
     if args.self_fix:
         os.environ["RD_FIXUP_IMPL"] = "self"   # read when a handle allocates its buffers
+    if args.fused_search:
+        os.environ["RD_SEARCH_IMPL"] = "fused"
     bds = [batch.BatchDemodulator(cfg, n_streams, n_blocks) for _ in range(max(2, args.resident))]
     bd = bds[0]
     t_h2d = time.perf_counter()
@@ -475,6 +479,7 @@ def main():
                                      else ("demod_ms", "total_ms"))},
             "completion": "pipelined" if args.pipelined else "per run",
             "fixup": "self" if os.environ.get("RD_FIXUP_IMPL", "").startswith("s") else "k_fixup",
+            "search": "fused" if os.environ.get("RD_SEARCH_IMPL", "").startswith("f") else "k_search",
             "fixup_runs_frac": round(cnt["fixup_runs"] * 32 / (n_streams * n_samples), 5),
             "packets_per_step": len(recs), "verified_vs_reference_fixtures": verified,
             "h2d_s": round(t_h2d, 3),

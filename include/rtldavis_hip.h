@@ -193,6 +193,13 @@ int rd_batch_get_timing(rd_batch *b, rd_timing *out);
  * results (rd_batch_results, rd_batch_get_timing, ...) records the event then.  A timed pipelined run has no
  * end-of-run event: rd_timing.total_ms covers the runs that have one (0 if none).  0 (default): off. */
 int rd_batch_set_pipelined(rd_batch *b, int enabled);
+/* Which forms of the kernels the last run took (it is waited for first; no counterpart in the reference - for tests and
+ * tools that must know that an opt-in form really ran and did not fall back): a mask of RD_FORM_*. */
+#define RD_FORM_ORDERED_TAIL 1u   /* records ordered and deduped on the device */
+#define RD_FORM_SELF_FIX 2u       /* RD_FIXUP_IMPL=self: no k_fixup launch */
+#define RD_FORM_FUSED_SEARCH 4u   /* RD_SEARCH_IMPL=fused: preamble test inside the demod kernel */
+#define RD_FORM_SECOND_PASS 8u    /* a list or bucket overflowed: search and slice ran a second time, in full */
+int rd_batch_last_run_forms(rd_batch *b, uint32_t *forms);
 /* Counters of the last run: 32-sample runs with at least one 8-sample group re-evaluated
  * exactly (guard band), raw preamble matches. */
 int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t *matches);

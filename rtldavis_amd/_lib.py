@@ -79,6 +79,7 @@ SIGNATURES = {
     "rd_batch_parsed": (C.c_int, [_P, C.POINTER(RdParsed), C.c_int, C.POINTER(C.c_int)]),
     "rd_batch_set_timing": (C.c_int, [_P, C.c_int]),
     "rd_batch_set_pipelined": (C.c_int, [_P, C.c_int]),
+    "rd_batch_last_run_forms": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "rd_batch_get_timing": (C.c_int, [_P, C.POINTER(RdTiming)]),
     "rd_batch_get_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rd_lut_execute": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),

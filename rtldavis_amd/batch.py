@@ -101,6 +101,13 @@ class BatchDemodulator:
         _lib.check(_lib.lib().rd_batch_get_timing(self._b, C.byref(t)))
         return {k: float(getattr(t, k)) for k, _ in t._fields_}
 
+    def last_run_forms(self) -> dict:
+        """Which forms the last run took (rd_batch_last_run_forms): for tests of the opt-in forms."""
+        f = C.c_uint32()
+        _lib.check(_lib.lib().rd_batch_last_run_forms(self._b, C.byref(f)))
+        return {"ordered_tail": bool(f.value & 1), "self_fix": bool(f.value & 2), "fused_search": bool(f.value & 4),
+                "second_pass": bool(f.value & 8)}
+
     def counters(self) -> dict:
         f, m = C.c_uint64(), C.c_uint64()
         _lib.check(_lib.lib().rd_batch_get_counters(self._b, C.byref(f), C.byref(m)))

@@ -297,6 +297,15 @@ struct rd_batch {
     // rd_mf_selffix) and no k_fixup is launched; the search kernel clears the next counter set.  self_run: the run in
     // flight was launched that way; self_redo: its (rare) overflow into the global list has been dealt with.
     bool self_fix = false, self_run = false;
+    // Fused search (RD_SEARCH_IMPL=fused): the demod kernel does the preamble test (rd_mf_search_tile) and k_search_rem
+    // the windows around the fix-up list's words and the chunk starts; ordered tail only.  d_extra: the kernel's extra
+    // arguments, one per counter set.
+    bool fused = false, fused_run = false;
+    bool second_pass = false;   // the run in flight needed a second search / slice pass (a list or bucket overflowed)
+    rd_mf_extra *d_extra = nullptr;
+    int2 *d_wmatch = nullptr;          // the demod waves' own match lists and their counts (fused search)
+    uint32_t *d_wcount = nullptr;
+    uint32_t last_launch[2] = {0, 0};  // tiles per chunk and waves of the last demod launch
     uint32_t self_pend_limit = 0;   // test hook RD_TEST_SELF_PEND: entries a wave keeps before the global list
     bool pipelined = false;
     bool deferred = false;          // the run in flight has no completion event yet (guarded by g_tail_mx)
@@ -408,6 +417,27 @@ static int batch_alloc(rd_batch *b) {
         HIPCHK(hipMalloc(&b->ord.tasks, lists * RD_ORD_LIST_STREAMS * 2 * RD_BUCKET * RD_OTASK_BYTES));
         HIPCHK(hipMalloc(&b->ord.wgtot, 2 * lists * sizeof(uint32_t)));
     }
+    {   // RD_SEARCH_IMPL=fused: see the field's comment; whole tiles only, every reported position >= 0
+        const char *si = getenv("RD_SEARCH_IMPL");
+        b->fused = si && si[0] == 'f' && b->ord_ok && !b->self_fix && b->n_samples % RD_TILE_SAMPLES == 0 && b->dc.B <= b->dc.L;
+        if (b->fused) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, b->device));
+            const size_t max_waves = (size_t)prop.multiProcessorCount * 8 * 4;  // the demod launch: at most 8 workgroups of 4 waves per CU
+            HIPCHK(hipMalloc(&b->d_wmatch, max_waves * RD_WAVE_MATCHES * sizeof(int2)));
+            HIPCHK(hipMalloc(&b->d_wcount, max_waves * sizeof(uint32_t)));
+            HIPCHK(hipMemset(b->d_wcount, 0, max_waves * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&b->d_extra, 2 * sizeof(rd_mf_extra)));
+            rd_mf_extra ex[2];
+            for (int k = 0; k < 2; k++) {
+                ex[k].wmatch = b->d_wmatch;
+                ex[k].wcount = b->d_wcount;
+                ex[k].p_hi = (int32_t)((long)(b->n_blocks + 1) * b->dc.B - b->dc.L);
+                ex[k].pad = 0;
+            }
+            HIPCHK(hipMemcpy(b->d_extra, ex, sizeof ex, hipMemcpyHostToDevice));
+        }
+    }
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
     HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
@@ -436,7 +466,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
-        hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.wgtot);
+        hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.wgtot); hipFree(b->d_extra); hipFree(b->d_wmatch); hipFree(b->d_wcount);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
@@ -536,9 +566,14 @@ static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = fals
     if (b->ord_ok && !b->ord_off && !(b->run_timing && b->run_detail)) {
         rd_ord_bufs ob = b->ord;
         ob.scount = batch_cnt(b) + RD_CNT_TOTAL;
+        // fused search: on the run's first pass the demod kernel has filled the buckets and k_search_rem adds what it
+        // left out; a second pass (some list overflowed) searches in full, from cleared buckets
+        rd_rem_args rem = {b->d_wmatch, b->d_wcount, b->last_launch[1], b->last_launch[0], b->d_fix, b->fix_cap, b->last_fix};
+        const bool use_rem = b->fused_run && may_defer && b->last_launch[0] > 0;
         b->ord_run = rd_launch_tail_ordered(lay, b->d_bits, b->bits_stride, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
                                             b->dc, b->n_blocks, ob, b->bucket_limit, b->d_recs, b->rec_cap, batch_cnt(b), st,
-                                            last_on_slice ? last : nullptr, zero_next, (uint32_t)b->cnt_stride) != 0;
+                                            last_on_slice ? last : nullptr, zero_next, (uint32_t)b->cnt_stride,
+                                            use_rem ? &rem : nullptr) != 0;
         if (b->ord_run) b->dense = 1;  // one record per task from index 0 - and already in the final order
     }
     if (!b->ord_run) {
@@ -605,23 +640,28 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     }
     // a pipelined run waiting on this stream is adopted by this run's demod kernel (its stop event)
     const bool adopt = batch_stream_has_tail(st);
-    const uint32_t dflags = b->self_fix ? RD_DEMOD_SELF_FIX : 0u;
+    // (the fused search feeds the ordered tail's buckets: only when that tail is going to run)
+    const bool want_fused = b->fused && b->ord_ok && !b->ord_off && !(b->timing && b->timing_detail) && !b->parse;
+    const uint32_t dflags = (b->self_fix ? RD_DEMOD_SELF_FIX : 0u) | (want_fused ? RD_DEMOD_FUSED_SEARCH : 0u);
+    const rd_mf_extra *extra = want_fused ? b->d_extra + b->cnt_set : nullptr;
     uint32_t honoured = 0;
     if (b->timing && b->fast_ok) {
         // the demod kernel's dispatch carries its own start / stop events (no marker packets)
-        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit);
+        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit, extra, b->last_launch);
         if (adopt && (rc = batch_adopt(st, b->ev[1]))) return rc;
     } else if (b->fast_ok && adopt) {
-        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit);
+        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit, extra, b->last_launch);
         if ((rc = batch_adopt(st, b->kfirst))) return rc;
     } else {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
-        if (b->fast_ok) honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit);
+        if (b->fast_ok) honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit, extra, b->last_launch);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
         if (adopt && (rc = batch_adopt(st, b->ev[1] ))) return rc;
     }
     // self-fix: the demod kernel's waves have patched their own words; the search kernel clears the next counter set
+    b->second_pass = false;
     b->self_run = b->fast_ok && (honoured & RD_DEMOD_SELF_FIX);
+    b->fused_run = b->fast_ok && (honoured & RD_DEMOD_FUSED_SEARCH);
     if (!b->self_run)
         rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
@@ -670,8 +710,12 @@ static int batch_finish(rd_batch *b) {
             // a stream with more matches than its bucket holds (or more records than the list): this input goes
             // through the unordered kernels and the host-side ordering, now and until the next upload
             b->ord_off = true;
+            if (dbg_host())
+                fprintf(stderr, "[rd] ordered tail overflow: flags %u (1 bucket, 2 records, 4 a demod wave's match list: %u entries), matches %u, fused %d\n",
+                        b->h_cnt[RD_CNT_OVF], b->h_cnt[RD_CNT_SLOTS - 1], b->h_cnt[RD_CNT_MATCH], (int)b->fused_run);
             const uint32_t zero[5] = {0, 0, 0, 0, 0};  // matches, boundary records, tasks, parsed, overflow
             HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
+            b->second_pass = true;
             int rc2 = batch_search_slice(b, st);
             if (rc2) return rc2;
             continue;
@@ -710,6 +754,7 @@ static int batch_finish(rd_batch *b) {
         // (the ordered tail's per-stream match counts hold the first pass's matches: its search starts from zero again)
         if (b->ord_ok && b->cnt_stride > RD_CNT_TOTAL)
             HIPCHK(hipMemsetAsync(batch_cnt(b) + RD_CNT_TOTAL, 0, (b->cnt_stride - RD_CNT_TOTAL) * sizeof(uint32_t), st));
+        b->second_pass = true;
         int rc2 = batch_search_slice(b, st);
         if (rc2) return rc2;
     }
@@ -899,6 +944,16 @@ extern "C" int rd_batch_get_timing(rd_batch *b, rd_timing *out) {
     b->ev_end.clear();
     b->last_timing = t;
     *out = t;
+    return RD_OK;
+}
+
+// Which forms the last run took (after it has completed): RD_FORM_* bits.
+extern "C" int rd_batch_last_run_forms(rd_batch *b, uint32_t *forms) {
+    if (!b || !forms) return fail(RD_ERR_ARG, "null argument");
+    int rc = batch_finish(b);
+    if (rc) return rc;
+    *forms = (b->ord_run ? RD_FORM_ORDERED_TAIL : 0u) | (b->self_run ? RD_FORM_SELF_FIX : 0u) |
+             (b->fused_run && !b->second_pass ? RD_FORM_FUSED_SEARCH : 0u) | (b->second_pass ? RD_FORM_SECOND_PASS : 0u);
     return RD_OK;
 }
 

@@ -624,6 +624,81 @@ __device__ __forceinline__ uint32_t rd_mf_search_probe(uint32_t ring_addr, uint3
     return m;
 }
 
+// RD_OPT_FSEARCH (RD_DEMOD_FUSED_SEARCH): the preamble test of py:171-188 inside this kernel, for the Davis
+// configuration.  A wave keeps a ring of 72 (word, flagged) pairs in LDS: eight entries of history (the last eight
+// words of its previous tile) and the tile's 64.  Lane wi evaluates the 32 positions of word wi - 7 of the tile
+// (window = that word and the seven behind it, the last one its own): 15 funnel shifts and the and / or tree, as
+// k_search does per output word.  What it reports: positions p <= p_hi whose window holds no FLAGGED word (a word with a
+// group on the fix-up list: its bits may still change) and lies in words this wave has seen - at a chunk's first tile
+// the ring's history is another stream's or another chunk's, and lanes 0-6 report nothing.  The positions left out are
+// exactly those k_search_rem (rd_kernels.hip) evaluates after k_fixup: the windows around every listed word and the
+// seven words in front of every chunk start.
+template <int S_, int P_, uint64_t PRE_>
+__device__ __forceinline__ uint32_t rd_mf_search_tile(uint32_t ring_addr, uint32_t wi, uint32_t word, uint32_t flagged) {
+    asm volatile("ds_write_b64 %0, %1" : : "v"(ring_addr + 8 * (8 + wi)), "v"(rd_u2v{word, flagged}) : "memory");
+    uint32_t r[8];
+    asm volatile("ds_read2_b32 %0, %4 offset0:2 offset1:4\n\tds_read2_b32 %1, %4 offset0:6 offset1:8\n\t"
+                 "ds_read2_b32 %2, %4 offset0:10 offset1:12\n\tds_read2_b32 %3, %4 offset0:14 offset1:16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(*(rd_u2v *)&r[0]), "=&v"(*(rd_u2v *)&r[2]), "=&v"(*(rd_u2v *)&r[4]), "=&v"(*(rd_u2v *)&r[6])
+                 : "v"(ring_addr + 8 * wi) : "memory");
+    uint32_t m = 0xFFFFFFFFu, any = 0;
+#pragma unroll
+    for (int k = 0; k < P_; k++) {
+        const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
+        const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[wj + 1 < 8 ? wj + 1 : 7], r[wj], sh) : r[wj];
+        if ((PRE_ >> k) & 1) m &= v; else any |= v;
+    }
+    return m & ~any;
+}
+// the rare part (some lane has a match in one tile of ~30 on noise), all lanes: bit b of m = position
+// 32 (word0 + wi - 7) + b of stream s.  A match goes to the WAVE's own list in global memory - plain stores, the
+// count in a scalar register: a returning atomic per match (on the stream's bucket counter) cost this kernel 8 % -
+// and k_search_rem moves the lists' entries into the per-stream buckets.
+template <int S_, int P_>
+__device__ __forceinline__ void rd_mf_emit_matches(uint32_t ring_addr, uint32_t wi, uint32_t m, uint32_t s, uint32_t word0,
+                                                   const rd_mf_extra *ex, uint32_t wave_id, uint32_t &nmatch) {
+    const int p_hi = ex->p_hi;
+    uint32_t keep = 0;
+    if (m) {
+        // the flags of the window's eight words (odd dwords of the ring's pairs): one wait
+        uint32_t f[8];
+        asm volatile("ds_read2_b32 %0, %4 offset0:3 offset1:5\n\tds_read2_b32 %1, %4 offset0:7 offset1:9\n\t"
+                     "ds_read2_b32 %2, %4 offset0:11 offset1:13\n\tds_read2_b32 %3, %4 offset0:15 offset1:17\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(*(rd_u2v *)&f[0]), "=&v"(*(rd_u2v *)&f[2]), "=&v"(*(rd_u2v *)&f[4]), "=&v"(*(rd_u2v *)&f[6])
+                     : "v"(ring_addr + 8 * wi) : "memory");
+        const uint32_t fo6 = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6], fo7 = fo6 | f[7];
+        static_assert(((P_ - 1) * S_) >> 5 == 6 && ((P_ - 1) * S_ + 31) >> 5 == 7, "a window ends in its seventh or eighth word");
+        uint32_t mm = m;
+        while (mm) {
+            const uint32_t b = (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1;
+            const int p = 32 * (int)(word0 + wi - 7) + (int)b;
+            const bool last7 = ((b + (uint32_t)((P_ - 1) * S_)) >> 5) == 7;
+            // (a flagged word in the window: k_search_rem reports the position, from the bits k_fixup leaves)
+            if (p <= p_hi && !(last7 ? fo7 : fo6)) keep |= 1u << b;
+        }
+    }
+    const uint32_t c = (uint32_t)__popc(keep);
+    uint32_t incl = c;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
+        if (rd_lane_now() >= sh) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t at = nmatch + incl - c;
+    int2 *mine = ex->wmatch + (size_t)wave_id * RD_WAVE_MATCHES;
+    while (keep) {
+        const uint32_t b = (uint32_t)__builtin_ctz(keep);
+        keep &= keep - 1;
+        if (at < RD_WAVE_MATCHES) mine[at] = int2{(int)s, 32 * (int)(word0 + wi - 7) + (int)b};
+        at++;
+    }
+    nmatch += __builtin_amdgcn_readfirstlane(total);
+}
+
 // In-kernel stamps (RD_OPT_STAMP, diagnostic library only; cdna_hip_programming.md section 7): one statement with
 // its own lgkmcnt(0), fenced against the scheduler on both sides.
 __device__ __forceinline__ uint64_t rd_stamp() {
@@ -655,6 +730,7 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 // stflags bits 16-23 (self-fix variant, test hook): entries a wave keeps before the global list (0 = RD_MF_PEND_SELF)
 #define RD_OPT_SELF 32    // self-fix variant (rd_mf_selffix): launched for RD_DEMOD_SELF_FIX, a kernel of its own so that
                           // the default kernel carries neither the call nor its scratch
+#define RD_OPT_FSEARCH 64 // fused-search variant (rd_mf_search_tile), launched for RD_DEMOD_FUSED_SEARCH
 #define RD_OPT_FPROBE 16  // diagnostic library: what an in-tile preamble test would cost (rd_mf_search_probe)
 #define RD_STAMP_WORDS 12
 template <int DBG, int NBUF, int OPT>
@@ -679,6 +755,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     uint8_t *xb = s_xb[wave];
     uint32_t *mypend = s_pend[wave];
     uint32_t npend = 0;
+    uint32_t fs_nmatch = 0;  // fused search: entries in this wave's own match list (wave-uniform)
 
     const int n = lane & 31, h = lane >> 5;
     // tap fragments: 6 x 4 registers for the whole kernel
@@ -977,6 +1054,17 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
             gmask = 0;
         }
         if (DBG == 1 || DBG == 2 || (DBG >= 4 && DBG != 7)) gmask = 0;  // (incl. 6, 9)
+        if constexpr ((OPT & RD_OPT_FSEARCH) != 0) {
+            __shared__ __attribute__((aligned(8))) uint32_t s_ring[RD_MF_WAVES][2 * 72];
+            const uint32_t ring_addr = rd_lds_addr(s_ring[wave]);
+            const uint32_t wi = (uint32_t)(2 * n + h);
+            const uint32_t flagged = gmask != 0 ? 1u : 0u;
+            uint32_t m = rd_mf_search_tile<14, 16, 0x91D3ull>(ring_addr, wi, word, flagged);
+            if (!carry && wi < 7) m = 0;  // no history of this stream in the ring: k_search_rem's boundary pass
+            if (rd_mf_any(m != 0)) rd_mf_emit_matches<14, 16>(ring_addr, wi, m, s, ti * 64, (const rd_mf_extra *)dbg_g, wave_id, fs_nmatch);
+            // the next tile's history (after the flags above have been read: LDS operations of a wave run in order)
+            if (wi >= 56) asm volatile("ds_write_b64 %0, %1" : : "v"(ring_addr + 8 * (wi - 56)), "v"(rd_u2v{word, flagged}) : "memory");
+        }
         const uint64_t fm = (any_flag || !carry) ? __ballot(gmask != 0) : 0;
         if (fm) {
             const uint32_t nf = (uint32_t)__popcll(fm);
@@ -1000,6 +1088,16 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
             rd_mf_selffix(pend_addr, npend, lay, counters + RD_CNT_QUEUE0 + (wave_id % RD_NQUEUE) * RD_QUEUE_STRIDE + RD_SELF_WORD);
         else
             rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
+    }
+    if constexpr ((OPT & RD_OPT_FSEARCH) != 0) {
+        if (rd_lane_now() == 0) {
+            const rd_mf_extra *ex = (const rd_mf_extra *)dbg_g;
+            ex->wcount[wave_id] = fs_nmatch < RD_WAVE_MATCHES ? fs_nmatch : RD_WAVE_MATCHES;
+            if (fs_nmatch > RD_WAVE_MATCHES) {  // the host searches in full; the count is left for its debug line
+                atomicOr(&counters[RD_CNT_OVF], 4u);
+                counters[RD_CNT_SLOTS - 1] = fs_nmatch;
+            }
+        }
     }
     if (STAMP && dbg_g) {  // a buffer of its own: nothing else in the kernel reads it
         const uint64_t t1 = rd_stamp(), r1 = rd_stamp_real();
@@ -1083,6 +1181,8 @@ struct rd_mf_launch_args {
     hipEvent_t ev_start, ev_stop;
     uint32_t stf_extra = 0;  // the self-fix variant's pending limit, or-ed into the kernel's stflags
     bool self_fix = false;
+    const rd_mf_extra *extra = nullptr;  // fused-search variant
+    uint32_t *chunk_out = nullptr;
     float *dbg_g;
 };
 
@@ -1113,6 +1213,8 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
     const uint64_t max_wgs = (uint64_t)P.n_cu * per_cu;
     if (wgs > max_wgs) wgs = max_wgs;
     float *dbg = a.dbg_g;
+    if (OPT & RD_OPT_FSEARCH) dbg = (float *)a.extra;  // (the fused-search variant reads its extra arguments there)
+    if (a.chunk_out) { a.chunk_out[0] = chunk; a.chunk_out[1] = (uint32_t)wgs * RD_MF_WAVES; }
 #ifdef RD_DIAG
     if (OPT & RD_OPT_STAMP) {
         const uint32_t nw = (uint32_t)wgs * RD_MF_WAVES;
@@ -1134,8 +1236,11 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
 }
 
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t pend_limit) {
+                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t pend_limit,
+                          const rd_mf_extra *extra, uint32_t *chunk_out) {
     rd_mf_launch_args a;
+    a.extra = (flags & RD_DEMOD_FUSED_SEARCH) ? extra : nullptr;
+    a.chunk_out = chunk_out;
     a.self_fix = (flags & RD_DEMOD_SELF_FIX) != 0;
     a.stf_extra = a.self_fix ? ((pend_limit & 0xFFu) << 16) : 0u;
     a.lay = lay;
@@ -1157,7 +1262,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
     }
 #ifdef RD_DIAG
     const rd_mf_params &P = rd_mf_get_params();
-    const int key = P.dbg * 1000 + P.nbuf * 100 + (P.opt | (a.self_fix ? RD_OPT_SELF : 0));  // (opt < 100)
+    const int key = P.dbg * 1000 + P.nbuf * 100 + (P.opt | (a.extra ? RD_OPT_FSEARCH : a.self_fix ? RD_OPT_SELF : 0));  // (opt < 100)
     switch (key) {
 #define RD_V(D, NB, O) case (D) * 1000 + (NB) * 100 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
         RD_V(0, 1, 0) RD_V(0, 1, 1) RD_V(0, 1, 2) RD_V(0, 1, 3) RD_V(0, 1, 4) RD_V(0, 1, 5) RD_V(0, 1, 6) RD_V(0, 1, 7)
@@ -1167,7 +1272,7 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
         RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
         RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
         RD_V(10, 1, 0) RD_V(10, 1, 4) RD_V(11, 1, 0) RD_V(11, 1, 4)
-        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10) RD_V(0, 1, 26) RD_V(1, 1, 10) RD_V(2, 1, 10) RD_V(6, 1, 10) RD_V(0, 1, 42)
+        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10) RD_V(0, 1, 26) RD_V(1, 1, 10) RD_V(2, 1, 10) RD_V(6, 1, 10) RD_V(0, 1, 42) RD_V(0, 1, 74)
         RD_V(0, 2, 0)
 #undef RD_V
         default:
@@ -1175,7 +1280,8 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
             abort();
     }
 #else
-    if (a.self_fix) rd_mf_launch_variant<0, 1, (RD_MF_PRODUCT_OPT | RD_OPT_SELF)>(a);
+    if (a.extra) rd_mf_launch_variant<0, 1, (RD_MF_PRODUCT_OPT | RD_OPT_FSEARCH)>(a);
+    else if (a.self_fix) rd_mf_launch_variant<0, 1, (RD_MF_PRODUCT_OPT | RD_OPT_SELF)>(a);
     else rd_mf_launch_variant<0, 1, RD_MF_PRODUCT_OPT>(a);
 #endif
 }

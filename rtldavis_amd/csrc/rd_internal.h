@@ -17,6 +17,16 @@ enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CN
 #define RD_SELF_WORD 1
 // rd_launch_demod flags
 #define RD_DEMOD_SELF_FIX 1u   /* a wave re-evaluates the groups it flagged itself when it has run out of tiles: no k_fixup launch */
+#define RD_DEMOD_FUSED_SEARCH 2u   /* the preamble test runs inside the demod kernel (Davis shape, per-stream buckets) */
+// What the fused-search variant of the demod kernel needs beyond its arguments (device memory, one per counter set;
+// the kernel receives its address in place of the test hook's output pointer)
+#define RD_WAVE_MATCHES 256  /* matches a demod wave keeps in its own list (16 on average at the bench workload, 70 at most) */
+struct rd_mf_extra {
+    int2 *wmatch;         // [demod wave][RD_WAVE_MATCHES] (stream, position): plain stores, no atomics in that kernel
+    uint32_t *wcount;     // [demod wave]: entries written (every wave of a launch writes its count, 0 included)
+    int32_t p_hi;         // last position to report (py:171-188: (n_blocks + 1) B - L)
+    int32_t pad;
+};
 // Behind the RD_CNT_SLOTS counters the host reads back: the demod kernel's work queues (chunks handed out beyond
 // the first one of every wave).  One counter word sustains ~90 atomics per microsecond, so there are RD_NQUEUE of
 // them, 256 bytes apart; wave w draws from queue w % RD_NQUEUE, which owns the chunks nwaves + q + RD_NQUEUE k.
@@ -61,13 +71,17 @@ int rd_ensure_device_public(void);
 // ev_start / ev_stop (optional): events that receive the kernel's own begin / end timestamps.
 // flags: RD_DEMOD_SELF_FIX; pend_limit (test hook, 0 = the kernel's own): entries a wave keeps before it falls back to the
 // global list.  Returns the flags the launched kernel honours (the round-1 VALU kernel of the diagnostic library: none).
+// extra (device address): required by RD_DEMOD_FUSED_SEARCH; chunk_out: receives the tiles per chunk the launch used
+// (the boundary pass of the reduced search needs it)
 uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t flags = 0, uint32_t pend_limit = 0);
+                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t flags = 0, uint32_t pend_limit = 0,
+                     const rd_mf_extra *extra = nullptr, uint32_t *chunk_out = nullptr);
 // The same stage with the FIR on the matrix pipe (rd_demod_mfma.hip); rd_launch_demod dispatches to it
 // unless RD_K1_IMPL=valu.  dbg_g (test hook): when given, the kernel also dumps g[tile][2048][2].
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr,
-                          uint32_t flags = 0, uint32_t pend_limit = 0);
+                          uint32_t flags = 0, uint32_t pend_limit = 0, const rd_mf_extra *extra = nullptr,
+                          uint32_t *chunk_out = nullptr);   // chunk_out[0] = tiles per chunk, [1] = waves launched
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
@@ -97,10 +111,20 @@ struct rd_ord_bufs {
     void *tasks = nullptr;       // [lists][RD_ORD_LIST_STREAMS * 2 RD_BUCKET] entries of RD_OTASK_BYTES: one dense list per 8 streams
     uint32_t *wgtot = nullptr;   // [2][lists] surviving tasks per list, matches per list; lists = ceil(n_streams / RD_ORD_LIST_STREAMS)
 };
+// rem (fused search): the demod kernel has done the preamble test; k_search_rem evaluates what it left out
+struct rd_rem_args {
+    const int2 *wmatch;        // the demod waves' own match lists (rd_mf_extra), scattered into the buckets here
+    const uint32_t *wcount;
+    uint32_t n_waves;          // waves of the demod launch
+    uint32_t chunk;            // tiles per chunk of the demod launch
+    const uint32_t *fix_list;  // the fix-up list k_fixup has just worked through
+    uint32_t fix_cap;
+    uint64_t expect_fix;       // the previous run's list length (grid size only)
+};
 int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
                            const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
                            uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop = nullptr,
-                           uint32_t *zero_next = nullptr, uint32_t zero_words = 0);
+                           uint32_t *zero_next = nullptr, uint32_t zero_words = 0, const rd_rem_args *rem = nullptr);
 // Slice + RSSI/SNR, one wave per match.  batch_mode = 1: position = absolute sample, calls derived
 // from it (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
 // lay.iq points at the newest block's first sample.

@@ -229,11 +229,14 @@ static const rd_k_params &rd_k_get_params() {
 }
 
 uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                         hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t flags, uint32_t pend_limit) {
+                         hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t flags, uint32_t pend_limit, const rd_mf_extra *extra,
+                         uint32_t *chunk_out) {
     const rd_k_params &P = rd_k_get_params();
     if (P.impl_mfma) {
-        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, pend_limit);
-        return flags & RD_DEMOD_SELF_FIX;
+        if (!extra) flags &= ~RD_DEMOD_FUSED_SEARCH;
+        if (flags & RD_DEMOD_FUSED_SEARCH) flags &= ~RD_DEMOD_SELF_FIX;  // (the reduced search reads the global fix-up list)
+        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, pend_limit, extra, chunk_out);
+        return flags & (RD_DEMOD_SELF_FIX | RD_DEMOD_FUSED_SEARCH);
     }
     const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
@@ -1308,11 +1311,14 @@ __global__ __launch_bounds__(32 * RD_ORD_WG_STREAMS) void k_classify_ord(const u
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int ob0 = (int)a[u].y;
+            // (equal keys = the same position reported twice - the fused search's reduced pass may do that: the copy
+            // in the lower bucket slot counts as the earlier one)
+            const bool lower = (int)(j0 + u) < sub;
             if (d[u].x == dw[0] && d[u].y == dw[1] && d[u].z == dw[2]) {
-                if ((a[u].x & 1u) && ob0 == b0 && a[u].z < k0) dup0 = true;
-                if ((a[u].x & 2u) && ob0 - 1 == b0 && a[u].w < k0) dup0 = true;
-                if ((a[u].x & 1u) && ob0 == b1 && a[u].z < k1) dup1 = true;
-                if ((a[u].x & 2u) && ob0 - 1 == b1 && a[u].w < k1) dup1 = true;
+                if ((a[u].x & 1u) && ob0 == b0 && (a[u].z < k0 || (a[u].z == k0 && lower))) dup0 = true;
+                if ((a[u].x & 2u) && ob0 - 1 == b0 && (a[u].w < k0 || (a[u].w == k0 && lower))) dup0 = true;
+                if ((a[u].x & 1u) && ob0 == b1 && (a[u].z < k1 || (a[u].z == k1 && lower))) dup1 = true;
+                if ((a[u].x & 2u) && ob0 - 1 == b1 && (a[u].w < k1 || (a[u].w == k1 && lower))) dup1 = true;
             }
         }
     }
@@ -1478,17 +1484,117 @@ __global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_search_rem: what is left of the search when the demod kernel has done the preamble test itself
+// (RD_DEMOD_FUSED_SEARCH, rd_demod_mfma.hip: rd_mf_search_tile).  That kernel reports every position whose 8-word
+// window holds no word on the fix-up list and does not reach back across the start of a chunk of tiles.  Here, after
+// k_fixup, one lane per item:
+//   item < n_chunks       the chunk that starts at tile item * chunk, if it is not a stream's first tile: all positions
+//                         of the seven words in front of it (the demod kernel's lanes 0-6 of that tile report nothing)
+//   item - n_chunks < n   fix-up list entry: the positions of the eight words that end with the listed word whose
+//                         window reaches it (their bits may have changed)
+//   the rest              entry e of demod wave w's own match list (rd_mf_extra): moved into its stream's bucket
+// A position in the windows of two listed words is reported twice (rare: 8 k words of 35 M are listed for a group
+// inside the guard band): k_classify_ord's dedupe drops the copy (same call, same bytes, same key - the lower bucket
+// slot wins).
+// ------------------------------------------------------------------------------------------
+template <int S_, int P_, uint64_t PRE_>
+__global__ __launch_bounds__(256) void k_search_rem(const uint32_t *bits, size_t bits_stride, int nwords, uint32_t tps,
+                                                    uint32_t total_tiles, uint32_t chunk, const uint32_t *fix_list,
+                                                    uint32_t fix_cap, const uint32_t *counters, int p_hi, int32_t *smatch,
+                                                    uint32_t *scount, const int2 *wmatch, const uint32_t *wcount,
+                                                    uint32_t n_waves) {
+    const uint32_t n_chunks = (total_tiles + chunk - 1) / chunk;
+    uint32_t n_fix = counters[RD_CNT_FIX];
+    if (n_fix > fix_cap) n_fix = fix_cap;  // (overflow: the host re-evaluates everything and searches in full)
+    const uint32_t n_list = n_chunks + n_fix;
+    const uint32_t items = n_list + n_waves * 64;  // 64 lanes per demod wave's list, whatever its length
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < items; item += gridDim.x * blockDim.x) {
+        uint32_t s;
+        int w_first, n_pos, need = -1, first_v = 0;
+        if (item >= n_list) {  // a demod wave's own list (a wave of this kernel = one list: its count is one broadcast load)
+            const uint32_t wv = (item - n_list) / 64;
+            const uint32_t cnt = wcount[wv];
+            for (uint32_t e = (item - n_list) % 64; e < cnt; e += 64) {
+                const int2 mp = wmatch[(size_t)wv * RD_WAVE_MATCHES + e];
+                const uint32_t slot = atomicAdd(&scount[mp.x], 1u);
+                if (slot < RD_BUCKET) smatch[(size_t)mp.x * RD_BUCKET + slot] = mp.y;
+            }
+            continue;
+        }
+        if (item < n_chunks) {
+            const uint32_t g = item * chunk;
+            s = g / tps;
+            const uint32_t ti = g - s * tps;
+            if (ti == 0) continue;
+            w_first = (int)(ti * (RD_TILE_SAMPLES / 32)) - 7;
+            n_pos = 7;
+        } else {
+            const uint32_t widx = fix_list[item - n_chunks] >> 4;
+            s = widx / (uint32_t)bits_stride;
+            need = (int)(widx - s * (uint32_t)bits_stride);
+            w_first = need - 7;
+            n_pos = 8;
+            // The first word of a chunk is always on the list (its first group has no predecessors in its wave): the
+            // seven words in front of it belong to that chunk's boundary item above - here only the word itself, or
+            // every match next to a chunk start would be reported twice and fill its stream's bucket.
+            const uint32_t wpt = RD_TILE_SAMPLES / 32;
+            if ((uint32_t)need % wpt == 0 && need > 0 && (s * tps + (uint32_t)need / wpt) % chunk == 0) first_v = 7;
+        }
+        const uint32_t *w = bits + (size_t)s * bits_stride;
+        uint32_t r[15];
+#pragma unroll
+        for (int j = 0; j < 15; j++) {
+            const int wi = w_first + j;
+            r[j] = (wi >= 0 && wi < nwords) ? w[wi] : 0u;
+        }
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const int pw = w_first + v;
+            if (v < first_v || v >= n_pos || pw < 0) continue;
+            uint32_t m = 0xFFFFFFFFu, any = 0;
+#pragma unroll
+            for (int k = 0; k < P_; k++) {
+                const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
+                const uint32_t x = sh ? __builtin_amdgcn_alignbit(r[v + wj + 1], r[v + wj], sh) : r[v + wj];
+                if ((PRE_ >> k) & 1) m &= x; else any |= x;
+            }
+            m &= ~any;
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const int p = 32 * pw + b;
+                if (p > p_hi) continue;
+                if (need >= 0 && pw + ((b + (P_ - 1) * S_) >> 5) < need) continue;  // its window ends before the listed word
+                const uint32_t slot = atomicAdd(&scount[s], 1u);
+                if (slot < RD_BUCKET) smatch[(size_t)s * RD_BUCKET + slot] = p;
+            }
+        }
+    }
+}
+
 // returns 1 when the ordered tail was launched (records: final, RD_CNT_TASKS of them from index 0), 0 when the
 // shape is not the one it is built for (the caller then uses rd_launch_search + rd_launch_slice)
 int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
                            const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
                            uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop, uint32_t *zero_next,
-                           uint32_t zero_words) {
+                           uint32_t zero_words, const rd_rem_args *rem) {
     if (!(cfg.S == 14 && cfg.P == 16 && cfg.K == 80 && cfg.pre_mask == 0x91D3ull) || n_bits >= (1l << 30) || cfg.B >= (1 << 24) ||
         !ob.smatch || lay.n_streams <= 0)
         return 0;
-    rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount,
-                     zero_next, zero_words);
+    if (rem) {  // the demod kernel has searched: the windows around the fix-up list's words and the chunk starts are left
+        const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
+        const uint32_t total = (uint32_t)lay.n_streams * tps;
+        const uint64_t items = (uint64_t)(total + rem->chunk - 1) / rem->chunk + std::max<uint64_t>(rem->expect_fix + rem->expect_fix / 4, 4096) +
+                               (uint64_t)rem->n_waves * 64;
+        const uint32_t wgs = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL((k_search_rem<14, 16, 0x91D3ull>), dim3(wgs), dim3(256), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32),
+                           tps, total, rem->chunk, rem->fix_list, rem->fix_cap, counters, (int)p_hi, ob.smatch, ob.scount,
+                           rem->wmatch, rem->wcount, rem->n_waves);
+    } else {
+        rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount,
+                         zero_next, zero_words);
+    }
     const uint32_t cg = (uint32_t)(lay.n_streams + RD_ORD_WG_STREAMS - 1) / RD_ORD_WG_STREAMS;
     hipLaunchKernelGGL((k_classify_ord<14, 80>), dim3(cg), dim3(32 * RD_ORD_WG_STREAMS), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32), cfg,
                        ob.smatch, ob.scount, lay.n_streams, bucket_limit < RD_BUCKET ? bucket_limit : (uint32_t)RD_BUCKET, n_calls,

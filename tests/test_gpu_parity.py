@@ -964,6 +964,43 @@ def test_self_fix_forms_agree_with_the_fixtures(dsp, batchmod, golden_streams, m
             assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
             assert sha(bd.bits(i)) == golden_streams[str(seed)]["bits_sha256"], (env, seed)
     assert bd.counters()["fixup_runs"] >= len(seeds)   # at least the first run of every stream
+    forms = bd.last_run_forms()
+    assert forms["self_fix"] and forms["second_pass"] == ("RD_TEST_SELF_PEND" in env)
+
+
+@pytest.mark.gpu
+def test_fused_search_equals_the_fixtures_and_the_c_oracle(dsp, batchmod, golden_streams, monkeypatch):
+    """RD_SEARCH_IMPL=fused: the demod kernel does the preamble test of dsp.py:171-188 itself (rd_mf_search_tile) and
+    k_search_rem evaluates what it leaves out - the windows around every word on the fix-up list and the seven words
+    in front of every chunk start.  (1) the 64 fixture streams; (2) bursts swept across a chunk start in steps of 12
+    samples (tile 16 of a stream = sample 32768: a chunk starts there whatever the chunk length, and its first word is
+    always on the fix-up list), so that matches fall into the boundary pass, into the window of a listed word, and
+    into both - against the C oracle: call, index, bytes, order."""
+    from oracle import c_oracle as CO
+    monkeypatch.setenv("RD_SEARCH_IMPL", "fused")
+    seeds = list(range(64))
+    raw = synth.synth_streams(seeds)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    for _ in range(2):
+        res = bd.demodulate(raw)
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+        assert bd.last_run_forms() == {"ordered_tail": True, "self_fix": False, "fused_search": True, "second_pass": False}
+    bd.close()
+    starts = [32768 - 448 - 300 + 12 * k for k in range(34)] + [8 * 8192 - 448 - 120 + 12 * k for k in range(14)]
+    swept = np.stack([synth.synth_stream(100 + k, start=st) for k, st in enumerate(starts)])
+    ocfg = CO.make_cfg(19200, 14, 16, 80, "1100101110001001", 8192)
+    want, _ = CO.demod_batch(swept, ocfg, threads=4, cap_per_stream=512)
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(starts), synth.BLOCKS_PER_STREAM)
+    res = bd.demodulate(swept)
+    assert bd.last_run_forms()["fused_search"] and not bd.last_run_forms()["second_pass"]
+    near = 0
+    for i in range(len(starts)):
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+        exp = [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
+        assert got == exp, (i, starts[i], len(got), len(exp))
+        near += sum(1 for p in want[i] if any(abs((p.call * 8192 + p.index - 8192) - edge) < 260 for edge in (32768, 65536)))
+    assert near >= 40   # the sweep did put matches next to the chunk starts (position = call * B + index - (L - B))
 
 
 @pytest.mark.gpu
