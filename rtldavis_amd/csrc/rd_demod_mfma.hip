@@ -514,6 +514,10 @@ __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t
             // non-temporal: the words are read next by another kernel, never again by this one (0.3-1.3 % faster;
             // RD_K1_STFLAGS & 1 switches to plain stores for A/B runs)
 #ifdef RD_DIAG
+            // RD_K1_STFLAGS & 512 (diagnostic library, WRONG results): three stores in four are skipped - what the whole
+            // kernel would gain if most tiles' words never had to leave the chip (profiles/r03_store_skip.txt)
+            if ((stflags & 512) && (((size_t)base >> 10) & 3) != 0) continue;
+            if ((stflags & 1024)) continue;  // ... and none at all
             // RD_K1_STFLAGS bits 3-5 (diagnostic library): the store's cache policy bits spelled out - which of them,
             // if any, changes what the word stores cost beside the tile loads (profiles/r03_store_policy.txt)
             if ((stflags >> 3) & 7) {
