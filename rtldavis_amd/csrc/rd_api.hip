@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
-#include <unordered_map>
+#include <map>
 
 #include <chrono>
 
@@ -315,7 +315,9 @@ struct rd_batch {
 
 // pipelined completion: launch stream -> the handle whose last run waits there for an adopter (see batch_adopt)
 static std::mutex g_tail_mx;
-static std::unordered_map<hipStream_t, rd_batch *> g_tail;
+// (keyed by device AND stream: the null stream of one device is not the null stream of another)
+typedef std::pair<int, hipStream_t> rd_tail_key;
+static std::map<rd_tail_key, rd_batch *> g_tail;
 
 static rd_layout batch_layout(const rd_batch *b) {
     rd_layout l;
@@ -456,7 +458,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
     if (!b) return;
     {
         std::lock_guard<std::mutex> g(g_tail_mx);  // a run still waiting to be adopted dies with its handle
-        auto it = g_tail.find(b->stream);
+        auto it = g_tail.find(rd_tail_key(b->device, b->stream));
         if (it != g_tail.end() && it->second == b) g_tail.erase(it);
         b->deferred = false;
     }
@@ -526,7 +528,7 @@ static int batch_readback(rd_batch *b, hipEvent_t after) {
 
 static int batch_flush_locked(rd_batch *p) {  // nobody adopted it: an event of its own
     if (!p->deferred) return RD_OK;
-    auto it = g_tail.find(p->stream);
+    auto it = g_tail.find(rd_tail_key(p->device, p->stream));
     if (it != g_tail.end() && it->second == p) g_tail.erase(it);
     p->deferred = false;
     int rc = use_device(p->device);
@@ -538,14 +540,14 @@ static int batch_flush(rd_batch *b) {
     std::lock_guard<std::mutex> g(g_tail_mx);
     return batch_flush_locked(b);
 }
-static bool batch_stream_has_tail(hipStream_t st) {
+static bool batch_stream_has_tail(int device, hipStream_t st) {
     std::lock_guard<std::mutex> g(g_tail_mx);
-    return g_tail.find(st) != g_tail.end();
+    return g_tail.find(rd_tail_key(device, st)) != g_tail.end();
 }
 // `carrier`: recorded when a kernel launched on `st` after the waiting run's tail has ended
-static int batch_adopt(hipStream_t st, hipEvent_t carrier) {
+static int batch_adopt(int device, hipStream_t st, hipEvent_t carrier) {
     std::lock_guard<std::mutex> g(g_tail_mx);
-    auto it = g_tail.find(st);
+    auto it = g_tail.find(rd_tail_key(device, st));
     if (it == g_tail.end()) return RD_OK;
     rd_batch *p = it->second;
     g_tail.erase(it);
@@ -590,12 +592,12 @@ static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = fals
     }
     if (defer) {  // the readback is enqueued by whoever launches next on this stream (batch_adopt) or by batch_flush
         std::lock_guard<std::mutex> g(g_tail_mx);
-        auto it = g_tail.find(st);
+        auto it = g_tail.find(rd_tail_key(b->device, st));
         if (it != g_tail.end() && it->second != b) {  // (cannot happen after rd_batch_run's adoption; kept safe)
             int rc = batch_flush_locked(it->second);
             if (rc) return rc;
         }
-        g_tail[st] = b;
+        g_tail[rd_tail_key(b->device, st)] = b;
         b->deferred = true;
         HIPCHK(hipGetLastError());
         return RD_OK;
@@ -639,7 +641,7 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         b->ev_runs++;
     }
     // a pipelined run waiting on this stream is adopted by this run's demod kernel (its stop event)
-    const bool adopt = batch_stream_has_tail(st);
+    const bool adopt = batch_stream_has_tail(b->device, st);
     // (the fused search feeds the ordered tail's buckets: only when that tail is going to run)
     const bool want_fused = b->fused && b->ord_ok && !b->ord_off && !(b->timing && b->timing_detail) && !b->parse;
     const uint32_t dflags = (b->self_fix ? RD_DEMOD_SELF_FIX : 0u) | (want_fused ? RD_DEMOD_FUSED_SEARCH : 0u);
@@ -648,15 +650,15 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     if (b->timing && b->fast_ok) {
         // the demod kernel's dispatch carries its own start / stop events (no marker packets)
         honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit, extra, b->last_launch);
-        if (adopt && (rc = batch_adopt(st, b->ev[1]))) return rc;
+        if (adopt && (rc = batch_adopt(b->device, st, b->ev[1]))) return rc;
     } else if (b->fast_ok && adopt) {
         honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit, extra, b->last_launch);
-        if ((rc = batch_adopt(st, b->kfirst))) return rc;
+        if ((rc = batch_adopt(b->device, st, b->kfirst))) return rc;
     } else {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
         if (b->fast_ok) honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit, extra, b->last_launch);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
-        if (adopt && (rc = batch_adopt(st, b->ev[1] ))) return rc;
+        if (adopt && (rc = batch_adopt(b->device, st, b->ev[1]))) return rc;
     }
     // self-fix: the demod kernel's waves have patched their own words; the search kernel clears the next counter set
     b->second_pass = false;
