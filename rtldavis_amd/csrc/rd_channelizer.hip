@@ -200,28 +200,36 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
     // epilogue: register e of tile tb holds row (e & 3) + 8 (e >> 2) + 4 h, column r; rows 2i, 2i+1 =
     // (re, im) of channel 16 (4 grp + wave) + i
     const float scale = gain * (1.0f / 127.6f);
+    // The output phasor e^{-j 2 pi frac(shift t / Fo)}: the exact remainder (two float64 mods and a sincospif) once
+    // per channel and lane, for the lane's first time block; the three blocks behind it are 32 output times further on
+    // each - a rotation by the channel's constant e^{-j 2 pi frac(32 shift / Fo)} (round 3: the remainder and the
+    // sincospif per OUTPUT were as long as the K loop).
+    const double fo = (double)out_rate;
 #pragma unroll
-    for (int tb = 0; tb < RD_CHAN_TB; tb++) {
-        const long t = t0 + 32 * tb + r;
-        if (t >= n_out) continue;
+    for (int e = 0; e < 16; e += 2) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ch = 16 * (RD_CHAN_RBG * grp + wave) + (row >> 1);
+        if (ch >= n_ch) continue;
+        const double shf = (double)shifts[ch];
+        const double rm0 = rd_chan_mod(shf * rd_chan_mod((double)(t0 + r), fo), fo);
+        const double inc = rd_chan_mod(shf * 32.0, fo);  // |shift| < 2^26: the product is exact
+        float sn, cs, si, ci;
+        sincospif(-2.0f * (float)(rm0 / fo), &sn, &cs);
+        sincospif(-2.0f * (float)(inc / fo), &si, &ci);
+        const float2 *dcc = dc + (size_t)ch * (RD_CHAN_EARLY + 1);
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int ch = 16 * (RD_CHAN_RBG * grp + wave) + (row >> 1);
-            if (ch >= n_ch) continue;
-            const float2 d0 = dc[(size_t)ch * (RD_CHAN_EARLY + 1) + (t < n_early ? (int)t : RD_CHAN_EARLY)];
-            const float re = __builtin_fmaf(acc[tb][e], tap_unscale, d0.x), im = __builtin_fmaf(acc[tb][e + 1], tap_unscale, d0.y);
-            // phase = -2 pi frac(shift t / Fo), the remainders exact in float64
-            const double fo = (double)out_rate;
-            const double tm = rd_chan_mod((double)t, fo);
-            const double rm = rd_chan_mod((double)shifts[ch] * tm, fo);
-            float sn, cs;
-            sincospif(-2.0f * (float)(rm / fo), &sn, &cs);
-            const float zr = (re * cs - im * sn) * scale, zi = (re * sn + im * cs) * scale;
-            const float qr = fminf(fmaxf(rintf(zr * 127.6f + 127.4f), 0.0f), 255.0f);
-            const float qi = fminf(fmaxf(rintf(zi * 127.6f + 127.4f), 0.0f), 255.0f);
-            const uint16_t o = (uint16_t)((uint32_t)qr | ((uint32_t)qi << 8));
-            *(uint16_t *)(out + (size_t)ch * out_stride + 2 * t) = o;
+        for (int tb = 0; tb < RD_CHAN_TB; tb++) {
+            const long t = t0 + 32 * tb + r;
+            if (t < n_out) {
+                const float2 d0 = dcc[t < n_early ? (int)t : RD_CHAN_EARLY];
+                const float re = __builtin_fmaf(acc[tb][e], tap_unscale, d0.x), im = __builtin_fmaf(acc[tb][e + 1], tap_unscale, d0.y);
+                const float zr = (re * cs - im * sn) * scale, zi = (re * sn + im * cs) * scale;
+                const float qr = fminf(fmaxf(rintf(zr * 127.6f + 127.4f), 0.0f), 255.0f);
+                const float qi = fminf(fmaxf(rintf(zi * 127.6f + 127.4f), 0.0f), 255.0f);
+                *(uint16_t *)(out + (size_t)ch * out_stride + 2 * t) = (uint16_t)((uint32_t)qr | ((uint32_t)qi << 8));
+            }
+            const float c2 = cs * ci - sn * si, s2 = sn * ci + cs * si;
+            cs = c2; sn = s2;
         }
     }
 }

@@ -977,6 +977,8 @@ def test_fused_search_equals_the_fixtures_and_the_c_oracle(dsp, batchmod, golden
     always on the fix-up list), so that matches fall into the boundary pass, into the window of a listed word, and
     into both - against the C oracle: call, index, bytes, order."""
     from oracle import c_oracle as CO
+    for k in ("RD_FIXUP_IMPL", "RD_TAIL_IMPL", "RD_SLICE_IMPL"):   # (forms that exclude this one, should the suite run under them)
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("RD_SEARCH_IMPL", "fused")
     seeds = list(range(64))
     raw = synth.synth_streams(seeds)
