@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=33, help="8192-sample blocks per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--live-traffic", type=int, default=1,
+                    help="1 (default, N = 1 only): after the timed region, measure roofline.traffic on THIS box - two child "
+                         "runs of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE: separate passes, counters "
+                         "only), ~30 s; 0 or any failure: the committed profiles/rNN_traffic.json whose kernel stamp matches")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--sustain", type=float, default=6.0,
                     help="seconds of back-to-back steps after the timed region (reported separately, never `value`; "
@@ -216,6 +220,50 @@ def wideband(args):
         "packets_recovered": f"{ok} of {len(info)}", "real_time_factor": round(n_out / CZ.OUT_RATE / dt, 1),
         "parity": "unpinned: rtldavis has no channelizer to compare with; checked against this repo's float64 model "
                   "(<= 1 LSB) and by recovering the injected packets through the pinned demodulator"}), flush=True)
+
+
+def live_traffic(args, budget_s: float = 150.0):
+    """HBM traffic of the demod kernel per launch, measured on this box: FETCH_SIZE and WRITE_SIZE in separate
+    `rocprofv3 --pmc` passes (counters only, the program straight after `--`), each a child run of this script with a
+    handful of steps; corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950, KiB -> bytes).
+    Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself under a profiler"
+    vals = {}
+    t_end = time.perf_counter() + budget_s
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rd_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-verify", "--sustain", "0", "--settle", "0",
+               "--live-traffic", "0", "--streams", str(args.streams), "--blocks", str(args.blocks)]
+        env = dict(os.environ)
+        env["TMPDIR"] = "/tmp"
+        try:
+            left = t_end - time.perf_counter()
+            if left < 10:
+                return None, "time budget spent"
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+            acc = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if "k_demod" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                            acc.append(float(r["Counter_Value"]))
+            if not acc:
+                return None, f"no {c} rows from rocprofv3"
+            vals[c] = sum(acc) / len(acc)
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+            return None, f"{c} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024), None
 
 
 def launch_ranks(args) -> int:
@@ -454,6 +502,19 @@ def main():
     except (OSError, KeyError, ValueError, TypeError, ImportError):
         pass
 
+    traffic_source = None
+    if traffic is not None:
+        traffic_source = "file: the committed profiles/rNN_traffic.json whose kernel stamp equals the library's"
+    if rank == 0 and world == 1 and args.live_traffic and not os.environ.get("RD_K1_IMPL"):
+        lt, why = live_traffic(args)
+        if lt is not None:
+            traffic, traffic_note = lt, None
+            traffic_source = ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this script on this box "
+                              "(FETCH_SIZE x 2: gfx950 correction)")
+        elif traffic is not None:
+            traffic_source += f" (live measurement skipped: {why})"
+        else:
+            traffic_note = (traffic_note + "; " if traffic_note else "") + f"live measurement skipped: {why}"
     if rank == 0:
         samples_step = n_streams * n_samples
         ms_step = elapsed / args.steps * 1e3
@@ -488,6 +549,8 @@ def main():
                          "note": "untimed steps in front of the warmup (clock ramp after the idle upload phase)"}
         if traffic_note:
             out["roofline"]["traffic_note"] = traffic_note
+        if traffic_source:
+            out["roofline"]["traffic_source"] = traffic_source
         if sustained:
             out["sustained"] = sustained
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only

@@ -27,7 +27,7 @@ for V in $VARS; do
   for K in ea_latency ea_stalls l2_hits l2_busy l1_latency utcl1 sq; do
     D=$OUT/${NAME}_$K
     rm -rf $D
-    timeout -k 10 180 rocprofv3 --pmc ${G[$K]} --output-format csv -d $D -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --sustain 0 --settle 0 > $D.log 2>&1
+    timeout -k 10 180 rocprofv3 --pmc ${G[$K]} --output-format csv -d $D -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --sustain 0 --settle 0 --live-traffic 0 > $D.log 2>&1
     RC=$?
     echo "[pmc_memside] $NAME $K rc $RC" | tee -a $OUT/progress.log
     if [ $RC -ge 124 ]; then exit $RC; fi

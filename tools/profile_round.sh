@@ -21,16 +21,16 @@ timeout -k 10 400 python3 $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench
 tail -c 400 $OUT/bench_default.json | tee -a $OUT/progress.log
 
 step "2/9 rocprofv3 --kernel-trace --stats of the same command"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --live-traffic 0 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 python3 $ROOT/tools/profile_collect.py stats $OUT/trace $OUT | tee -a $OUT/progress.log
 
 step "3/9 SQ counters (own run)"
-timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --sustain 0 > $OUT/pmc_sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --sustain 0 --live-traffic 0 > $OUT/pmc_sq.log 2>&1
 python3 $ROOT/tools/profile_collect.py pmc $OUT/pmc_sq > $OUT/pmc_sq_counters.csv
 
 step "4/9 HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustain 0 > $OUT/pmc_$C.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustain 0 --live-traffic 0 > $OUT/pmc_$C.log 2>&1
 done
 python3 $ROOT/tools/profile_collect.py traffic $OUT $COMMIT > $OUT/traffic.json
 cat $OUT/traffic.json | tee -a $OUT/progress.log
