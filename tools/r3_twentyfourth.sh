@@ -8,8 +8,8 @@ rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
 export GPU_FORCE_BLIT_COPY_SIZE=0
 echo "[r3y] default bench" | tee -a $OUT/progress.log
-/usr/bin/time -v timeout -k 10 500 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; RC=$?
-grep -E "Elapsed|Maximum resident" $OUT/bench_default.err | tee -a $OUT/progress.log
+T0=$(date +%s); timeout -k 10 500 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; RC=$?
+echo "wall seconds: $(( $(date +%s) - T0 ))" | tee -a $OUT/progress.log
 python3 - $OUT/bench_default.json <<'PY' | tee -a $OUT/progress.log
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
