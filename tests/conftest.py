@@ -17,7 +17,8 @@ def pytest_configure(config):
     # the in-tree shared library is a build artefact (git-ignored): build it when it is missing
     # (hipcc cross-compiles for gfx950 without a GPU); tests never fall back to anything else
     so = os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.so")
-    if not os.path.exists(so):
+    stamp = os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.stamp")   # (written by the same make target)
+    if not os.path.exists(so) or not os.path.exists(stamp):
         import subprocess
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rtldavis_amd", "csrc")])
 
