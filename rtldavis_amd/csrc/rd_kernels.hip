@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(32 * RD_ORD_WG_STREAMS) void k_classify_ord(const u
 // (8-stream lists dealt out one by one left the slowest wave with half as many again).  An entry's final position: the
 // totals of the lists in front (summed here: at most n_streams / 8 words, one round of loads) plus its index.
 #define RD_ORD_RSSI_WAVES (RD_ORD_SUPER * RD_ORD_LIST_STREAMS)
-__global__ __launch_bounds__(256) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, const rd_otask *tasks, const uint32_t *wgtot,
+__global__ __launch_bounds__(256, 4) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, const rd_otask *tasks, const uint32_t *wgtot,
                                                   int n_lists, int nbytes, rd_packet *recs, uint32_t rec_cap,
                                                   uint32_t *counters) {
     const int lane = threadIdx.x & 63;
