@@ -17,21 +17,24 @@
 // Kernel: f16 MFMA (v_mfma_f32_32x32x16_f16) - the one dense contraction in this repo.  As a real
 // GEMM, C[m][n] = sum_kappa A[m][kappa] B[kappa][n] with
 //   m     = 2 c + part  (part 0 = re, 1 = im of channel c; rows 2c, 2c+1 land in one lane's registers)
-//   kappa = 2 i + comp  (comp 0 = I, 1 = Q of window sample i = T-1-k, i.e. ascending in memory)
-//   A[2c][2i] = g_r, A[2c][2i+1] = -g_i, A[2c+1][2i] = g_i, A[2c+1][2i+1] = g_r    (g = g_c[T-1-i])
-//   B[2i + comp][n] = b_comp[D (t0 + n) - (T-1) + i] - 128
-// The samples are 8-bit integers: b - 128 is EXACT in f16, and lut(b) = (b - 128 + 0.6) / 127.6, so
-// z = (sum + 0.6 (1 + j) sum_k g_c[k]) / 127.6 with the second term a per-channel constant (a short
+//   kappa = 2 i + comp  (comp 0 = I, 1 = Q of window sample i, ascending in memory; inside a lane's four samples the
+//           fragment's elements are ordered I0 I1 Q0 Q1 | I2 I3 Q2 Q3, which is what one v_and + one v_perm per dword give)
+//   A[2c][2i] = g_r, A[2c][2i+1] = -g_i, A[2c+1][2i] = g_i, A[2c+1][2i+1] = g_r    (g = g_c[T-i], zero outside 0..T-1)
+//   B[2i + comp][n] = b_comp[D (t0 + n) - T + i] 2^-24
+// The samples are bytes: read as an f16 bit pattern, a byte in the low half of a 16-bit lane IS the subnormal
+// b 2^-24 (round 3; the matrix pipe takes subnormal inputs at face value and at full rate,
+// profiles/r02_ubench_mfma_subnormal.txt), and lut(b) = (b - 127.4) / 127.6, so
+// z = (sum - 127.4 (1 + j) sum_k g_c[k]) / 127.6 with the second term a per-channel constant (a short
 // table for the first outputs of a capture, whose history is zero).  The taps, scaled by a power of two
 // so that the largest sits just below 2^15, are split into TWO f16 terms (hi + lo: 22 bits; round 1 used
 // three bf16 terms for 24), i.e. two MFMAs per tile and K step into the same fp32 accumulator: products
 // are exact, sums are fp32, the tap error 2^-22 relative - two orders below the fp32 accumulation's.
 // 8 T flops per output: 113 GFLOP for one second of 51 channels; HBM traffic is 81 MB.
 // A workgroup = 4 waves = 128 output times x a group of 4 row blocks (64 channels); wave w owns row
-// block w and the four 32-time blocks (4 accumulator tiles).  The 127 D + T input samples are staged
-// once in LDS as f16 pairs (I - 128, Q - 128) - 52 KiB, three workgroups per CU - so a B fragment is
-// one aligned ds_read_b128 (D = 100: lane stride 100 dwords, conflict-free).  A wave only needs its
-// own row block's A fragments (2 terms x 16 bytes per lane and K step): they come straight from L2
+// block w and the four 32-time blocks (4 accumulator tiles).  The 127 D + T + 8 input samples are staged
+// once in LDS as they are, two bytes each - 26 KiB (round 2: f16 pairs, 52 KiB and three workgroups per CU) - so a B
+// fragment is one aligned ds_read_b64 (D = 100: lane stride 50 dwords, conflict-free) and four v_perm.  A wave only
+// needs its own row block's A fragments (2 terms x 16 bytes per lane and K step): they come straight from L2
 // into registers two K steps ahead; the main loop has no barrier.
 // Measured (one second of capture, 27 M samples -> 51 x 270 k): 0.25 ms = 4000x real time.
 // On the way: fp32 VALU kernel 0.88 ms (64 TFLOP/s, bound by the CU's LDS pipe: every fma needed
@@ -64,7 +67,12 @@ extern int rd_ensure_device_public(void);
 #ifndef RD_CHAN_NPF
 #define RD_CHAN_NPF 2                       // A chunks in flight in registers
 #endif
+#ifndef RD_CHAN_MINWAVES
+#define RD_CHAN_MINWAVES 4                  // waves per SIMD the register allocation aims at (26 KiB of LDS admit 6)
+#endif
 #define RD_CHAN_EARLY 64                    // outputs per channel with a partial-history DC term kept in a table
+#define RD_CHAN_DCN (RD_CHAN_EARLY + 2)     // table entries per channel: the early DC terms, the steady one, and the
+                                            // phasor of 32 output times e^{-j 2 pi frac(32 shift / Fo)} (cos, sin)
 
 typedef float rd_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 rd_f16x8 __attribute__((ext_vector_type(8)));
@@ -77,7 +85,7 @@ struct rd_chan {
     int n_early = 0;               // outputs whose window reaches before the capture: ceil((t_pad - 1) / D)
     float tap_unscale = 1.0f;      // 2^-s: the taps in h_amat are scaled by 2^s
     std::vector<uint16_t> h_amat;  // f16 A operand in fragment order [group][K step][term][row block][lane][8]
-    std::vector<float> h_dc;       // [channel][RD_CHAN_EARLY + 1][2]: 0.6 (1+j) sum of the taps a given output sees
+    std::vector<float> h_dc;       // [channel][RD_CHAN_DCN][2]: -127.4 (1+j) sum of the taps a given output sees; the 32-step phasor
     std::vector<int64_t> shifts;   // Hz, reduced mod out_rate
     uint16_t *d_amat = nullptr;
     float *d_dc = nullptr;
@@ -98,38 +106,42 @@ __device__ __forceinline__ double rd_chan_mod(double x, double m) {
 }
 
 // T is the padded tap count (multiple of RD_CHAN_KC, zero taps appended), D a multiple of 4.
-__global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
+// Round 3: the window is staged as the RAW bytes - a byte in the low half of a 16-bit lane IS the f16 subnormal
+// k 2^-24, which the matrix pipe takes at face value and at full rate (the demod kernel's operands, rd_mfma.h) - 2
+// bytes per sample in LDS instead of an f16 pair's 4 (26 KiB per workgroup instead of 52), no conversion arithmetic in
+// the staging, and the 127.4 offset of the LUT as a per-channel constant (-127.4 sum of the taps an output sees).  The
+// window starts one sample early, at n0 = D t0 - T, a multiple of 8 samples: 16-byte loads, 16-byte LDS writes and
+// 8-byte fragment reads are all aligned; the price is one more K step (the leading tap of it is zero).
+__global__ __launch_bounds__(256, RD_CHAN_MINWAVES) void k_channelize(const uint8_t *__restrict__ wide, long n_wide,
                                                     const uint4 *__restrict__ amat, const float2 *__restrict__ dc,
                                                     const int64_t *shifts, int T, int D, int n_ch, int n_early,
                                                     long out_rate, float gain, float tap_unscale, long n_out,
                                                     uint8_t *out, size_t out_stride, int xs_bytes) {
     extern __shared__ uint8_t lds[];
-    uint8_t *xs = lds;                            // window samples 0 .. span-1 as f16 pairs (I - 128, Q - 128)
+    uint8_t *xs = lds;                            // window samples 0 .. span-1, two bytes each (I, Q)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // = row block
     const int r = lane & 31, h = lane >> 5;
     const long t0 = (long)blockIdx.x * RD_CHAN_TT;
     const int grp = blockIdx.y;
-    // stage samples n_base .. n_base + span - 1, n_base = D t0 - (T - 1); a sample before the capture
-    // (or after it) is the byte 128 = value 0.  16-byte loads from an aligned start, four in flight.
-    const long n_base = (long)D * t0 - (T - 1);
-    const int span = (RD_CHAN_TT - 1) * D + T;
-    const long n_al = n_base - (((n_base % 8) + 8) % 8);
-    const int n_vec = (int)((n_base + span - n_al + 7) / 8);
+    // stage samples n0 .. n0 + span - 1; a sample before the capture (or after it) is the byte 0 = no contribution
+    const long n0 = (long)D * t0 - T;
+    const int span = (RD_CHAN_TT - 1) * D + T + RD_CHAN_KC;
+    const int n_vec = (span + 7) / 8;
     for (int q0 = threadIdx.x; q0 < n_vec; q0 += 4 * blockDim.x) {
         uint4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int q = q0 + u * blockDim.x;
-            const long n = n_al + 8L * q;
-            v[u] = uint4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+            const long n = n0 + 8L * q;
+            v[u] = uint4{0u, 0u, 0u, 0u};
             if (q < n_vec) {
                 if (n >= 0 && n + 8 <= n_wide) {
                     v[u] = *(const uint4 *)(wide + 2 * n);
                 } else {
                     uint16_t e[8];
 #pragma unroll
-                    for (int w = 0; w < 8; w++) e[w] = (n + w >= 0 && n + w < n_wide) ? *(const uint16_t *)(wide + 2 * (n + w)) : (uint16_t)0x8080;
+                    for (int w = 0; w < 8; w++) e[w] = (n + w >= 0 && n + w < n_wide) ? *(const uint16_t *)(wide + 2 * (n + w)) : (uint16_t)0;
                     v[u] = uint4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
                                  (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
                 }
@@ -138,22 +150,11 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int q = q0 + u * blockDim.x;
-            if (q >= n_vec) continue;
-            const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-            const int i0 = (int)(n_al + 8L * q - n_base);
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const int i = i0 + w;
-                const uint32_t iq = (w4[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
-                // (I - 128, Q - 128) as an f16 pair: small integers, exact
-                const float fi = (float)(iq & 0xFF) - 128.0f, fq = (float)(iq >> 8) - 128.0f;
-                if (i >= 0 && i < span)
-                    ((uint32_t *)xs)[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(fi, fq));
-            }
+            if (q < n_vec) *(uint4 *)(xs + 16 * q) = v[u];
         }
     }
-    const uint4 *asrc = amat + (size_t)grp * (T / 8) * (RD_CHAN_Q_BYTES / 16);
-    const int n_chunks = T / RD_CHAN_KC;
+    const int n_chunks = T / RD_CHAN_KC + 1;
+    const uint4 *asrc = amat + (size_t)grp * n_chunks * (RD_CHAN_Q_BYTES / 16);
     // A wave only ever needs ITS row block's A fragments (RD_CHAN_TERMS x 16 bytes per lane and K step):
     // they come straight from L2 into registers, NPF steps ahead - no LDS, no barrier in the loop.
     constexpr int NPF = RD_CHAN_NPF;
@@ -171,8 +172,9 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
     for (int b = 0; b < RD_CHAN_TB; b++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[b][e] = 0.0f;
-    // B fragment of (time block tb, K step q): window samples 8q + 4h .. +3 of column 32 tb + r
-    const uint8_t *xl = xs + 4 * (D * r + 4 * h);
+    // B fragment of (time block tb, K step q): window samples 8q + 4h .. +3 of column 32 tb + r = eight bytes
+    // (I0 Q0 I1 Q1 | I2 Q2 I3 Q3) -> eight 16-bit lanes
+    const uint8_t *xl = xs + 2 * (D * r + 4 * h);
     for (int c0 = 0; c0 < n_chunks; c0 += NPF) {
 #pragma unroll
         for (int s = 0; s < NPF; s++) {
@@ -188,9 +190,19 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
                 for (int term = 0; term < RD_CHAN_TERMS; term++)
                     pre[s][term] = amine[(size_t)(qn * RD_CHAN_TERMS + term) * (RD_CHAN_RBG * 64)];
             }
+            uint2 raw[RD_CHAN_TB];
+#pragma unroll
+            for (int tb = 0; tb < RD_CHAN_TB; tb++) raw[tb] = *(const uint2 *)(xl + 2 * (D * 32 * tb + 8 * q));
 #pragma unroll
             for (int tb = 0; tb < RD_CHAN_TB; tb++) {
-                const rd_f16x8 bfrag = __builtin_bit_cast(rd_f16x8, *(const uint4 *)(xl + 4 * (D * 32 * tb + 8 * q)));
+                uint4 f;
+                // element order (I0 I1 Q0 Q1 | I2 I3 Q2 Q3) - the A fragments are laid out to match: the even bytes of a
+                // dword by one v_and, the odd ones by one v_perm (selector 0x0c = a zero byte), as in rd_mf_frag
+                f.x = raw[tb].x & 0x00FF00FFu;
+                f.y = __builtin_amdgcn_perm(0u, raw[tb].x, 0x0c030c01u);
+                f.z = raw[tb].y & 0x00FF00FFu;
+                f.w = __builtin_amdgcn_perm(0u, raw[tb].y, 0x0c030c01u);
+                const rd_f16x8 bfrag = __builtin_bit_cast(rd_f16x8, f);
 #pragma unroll
                 for (int term = 0; term < RD_CHAN_TERMS; term++)
                     acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[term], bfrag, acc[tb], 0, 0, 0);
@@ -200,23 +212,37 @@ __global__ __launch_bounds__(256) void k_channelize(const uint8_t *__restrict__ 
     // epilogue: register e of tile tb holds row (e & 3) + 8 (e >> 2) + 4 h, column r; rows 2i, 2i+1 =
     // (re, im) of channel 16 (4 grp + wave) + i
     const float scale = gain * (1.0f / 127.6f);
-    // The output phasor e^{-j 2 pi frac(shift t / Fo)}: the exact remainder (two float64 mods and a sincospif) once
-    // per channel and lane, for the lane's first time block; the three blocks behind it are 32 output times further on
-    // each - a rotation by the channel's constant e^{-j 2 pi frac(32 shift / Fo)} (round 3: the remainder and the
-    // sincospif per OUTPUT were as long as the K loop).
-    const double fo = (double)out_rate;
+    // The output phasor e^{-j 2 pi frac(shift t / Fo)}: the exact remainder once per channel and lane, for the lane's
+    // first time block (one float64 product, a quotient by multiplication, the hardware sine and cosine); the three
+    // blocks behind it are 32 output times further on each - a rotation by the channel's constant from the table.
+    // (Round 3, from the counters: the kernel's vector work - two float64 divisions and a sincospif per OUTPUT - took
+    // as long as its MFMAs, and the two do not overlap.)
+    const double fo = (double)out_rate, inv_fo = 1.0 / fo;
+    // (t0 + r) mod Fo once per lane: a float estimate of the quotient is off by one at most
+    long tm = t0 + r;
+    {
+        const long qe = (long)floorf((float)tm * (float)inv_fo);
+        tm -= qe * out_rate;
+        if (tm < 0) tm += out_rate;
+        if (tm >= out_rate) tm -= out_rate;
+    }
 #pragma unroll
     for (int e = 0; e < 16; e += 2) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
         const int ch = 16 * (RD_CHAN_RBG * grp + wave) + (row >> 1);
         if (ch >= n_ch) continue;
-        const double shf = (double)shifts[ch];
-        const double rm0 = rd_chan_mod(shf * rd_chan_mod((double)(t0 + r), fo), fo);
-        const double inc = rd_chan_mod(shf * 32.0, fo);  // |shift| < 2^26: the product is exact
-        float sn, cs, si, ci;
-        sincospif(-2.0f * (float)(rm0 / fo), &sn, &cs);
-        sincospif(-2.0f * (float)(inc / fo), &si, &ci);
-        const float2 *dcc = dc + (size_t)ch * (RD_CHAN_EARLY + 1);
+        // frac(shift t / Fo) exactly: shift, tm < Fo < 2^26, the product is exact in float64; the quotient from a
+        // multiplication by 1 / Fo is off by one at most
+        const double x = (double)shifts[ch] * (double)tm;
+        double rm = __builtin_fma(-floor(x * inv_fo), fo, x);
+        if (rm < 0.0) rm += fo;
+        if (rm >= fo) rm -= fo;
+        // v_sin_f32 / v_cos_f32 take their argument in revolutions
+        const float turns = -(float)(rm * inv_fo);
+        float sn = __builtin_amdgcn_sinf(turns), cs = __builtin_amdgcn_cosf(turns);
+        const float2 *dcc = dc + (size_t)ch * RD_CHAN_DCN;
+        const float2 rot = dcc[RD_CHAN_EARLY + 1];
+        const float ci = rot.x, si = rot.y;
 #pragma unroll
         for (int tb = 0; tb < RD_CHAN_TB; tb++) {
             const long t = t0 + 32 * tb + r;
@@ -262,8 +288,8 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
         !(cfg->gain > 0.0))
         return rd_fail_msg(RD_ERR_ARG, "channelizer config out of range (decim: a multiple of 4)");
     const int t_pad = (cfg->n_taps + RD_CHAN_KC - 1) / RD_CHAN_KC * RD_CHAN_KC;
-    const size_t span = (size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad;
-    if (4 * span + 16 > 160 * 1024)
+    const size_t span = (size_t)(RD_CHAN_TT - 1) * cfg->decim + t_pad + RD_CHAN_KC;
+    if (2 * span + 16 > 160 * 1024)
         return rd_fail_msg(RD_ERR_ARG, "decim x 255 + n_taps samples do not fit the 160 KiB LDS");
     const int n_early = (t_pad - 1 + cfg->decim - 1) / cfg->decim;
     if (n_early > RD_CHAN_EARLY) return rd_fail_msg(RD_ERR_ARG, "n_taps / decim too large");
@@ -273,9 +299,9 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
     h->t_pad = t_pad;
     h->n_early = n_early;
     h->n_groups = (cfg->n_channels + 16 * RD_CHAN_RBG - 1) / (16 * RD_CHAN_RBG);
-    const int n_q = t_pad / 8;
+    const int n_q = t_pad / 8 + 1;  // the window starts one sample early (aligned): one more K step
     h->h_amat.assign((size_t)h->n_groups * n_q * (RD_CHAN_Q_BYTES / 2), 0);
-    h->h_dc.assign((size_t)cfg->n_channels * (RD_CHAN_EARLY + 1) * 2, 0.0f);
+    h->h_dc.assign((size_t)cfg->n_channels * RD_CHAN_DCN * 2, 0.0f);
     h->shifts.resize(cfg->n_channels);  // shift mod Fo in [0, Fo): all the output phasor needs
     for (int c = 0; c < cfg->n_channels; c++) h->shifts[c] = ((shift_hz[c] % cfg->out_rate) + cfg->out_rate) % cfg->out_rate;
     const double wide_rate = (double)cfg->out_rate * cfg->decim;
@@ -288,7 +314,7 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
     if (sexp > 60) sexp = 60;
     if (sexp < -60) sexp = -60;
     const double tap_scale = std::ldexp(1.0, sexp);
-    h->tap_unscale = (float)std::ldexp(1.0, -sexp);
+    h->tap_unscale = (float)std::ldexp(1.0, -sexp + 24);  // (+24: the samples enter as k 2^-24)
     std::vector<double> gr(t_pad), gi(t_pad);
     for (int c = 0; c < cfg->n_channels; c++) {
         for (int k = 0; k < t_pad; k++) {
@@ -303,21 +329,28 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
             gr[k] = (double)(float)(taps[k] * cos(ph));  // the fp32 taps are the definition's taps on the device
             gi[k] = (double)(float)(taps[k] * sin(ph));
         }
-        // DC term: lut(b) = (b - 128 + 0.6) / 127.6; output t sees taps k <= D t (zero history before)
+        // DC term: output t sees taps k <= D t (zero history before)
         double sr = 0.0, si = 0.0;
         int kdone = 0;
         for (int t = 0; t <= RD_CHAN_EARLY; t++) {
             const long kmax = t < RD_CHAN_EARLY ? (long)cfg->decim * t : (long)t_pad - 1;
             for (; kdone < t_pad && kdone <= kmax; kdone++) { sr += gr[kdone]; si += gi[kdone]; }
-            // 0.6 (1 + j)(sr + j si) = 0.6 ((sr - si) + j (sr + si))
-            h->h_dc[((size_t)c * (RD_CHAN_EARLY + 1) + t) * 2] = (float)(0.6 * (sr - si));
-            h->h_dc[((size_t)c * (RD_CHAN_EARLY + 1) + t) * 2 + 1] = (float)(0.6 * (sr + si));
+            // lut(b) = (b - 127.4) / 127.6 and the kernel sums g b: the constant is -127.4 (1 + j)(sr + j si)
+            h->h_dc[((size_t)c * RD_CHAN_DCN + t) * 2] = (float)(-127.4 * (sr - si));
+            h->h_dc[((size_t)c * RD_CHAN_DCN + t) * 2 + 1] = (float)(-127.4 * (sr + si));
+        }
+        {   // the rotation that takes the output phasor 32 output times on (exact remainder, float64 sin / cos)
+            const long inc = (long)(((__int128)h->shifts[c] * 32) % cfg->out_rate);
+            const double ph = -2.0 * M_PI * ((double)inc / (double)cfg->out_rate);
+            h->h_dc[((size_t)c * RD_CHAN_DCN + RD_CHAN_EARLY + 1) * 2] = (float)cos(ph);
+            h->h_dc[((size_t)c * RD_CHAN_DCN + RD_CHAN_EARLY + 1) * 2 + 1] = (float)sin(ph);
         }
         // rows 2c (re) and 2c+1 (im); kappa = 2 i + comp, window sample i = t_pad - 1 - k
         const int grp = c / (16 * RD_CHAN_RBG), rb = (c / 16) % RD_CHAN_RBG, r0 = 2 * (c % 16);
-        for (int i = 0; i < t_pad; i++) {
-            const int k = t_pad - 1 - i;
-            const int q = i / 8, hh = (i % 8) / 4, j0 = 2 * (i % 4);  // lane half and element pair of this sample
+        for (int i = 0; i < 8 * n_q; i++) {   // window sample i of a column <-> tap k = t_pad - i (the window starts at D t - t_pad)
+            const int k = t_pad - i;
+            if (k < 0 || k >= t_pad) continue;  // (zero taps: the entries stay 0)
+            const int q = i / 8, hh = (i % 8) / 4, s4 = i % 4;  // K step, lane half, sample within the lane's four
             for (int part = 0; part < 2; part++)
                 for (int comp = 0; comp < 2; comp++) {
                     const double a = part == 0 ? (comp == 0 ? gr[k] : -gi[k]) : (comp == 0 ? gi[k] : gr[k]);
@@ -326,7 +359,8 @@ extern "C" int rd_chan_create(const rd_chan_config *cfg, const double *taps, con
                     const uint16_t term[RD_CHAN_TERMS] = {hi, lo};
                     const int lane = 32 * hh + r0 + part;
                     for (int tm = 0; tm < RD_CHAN_TERMS; tm++) {
-                        const size_t at = (((((size_t)grp * n_q + q) * RD_CHAN_TERMS + tm) * RD_CHAN_RBG + rb) * 64 + lane) * 8 + j0 + comp;
+                        // element position inside the fragment: (I0 I1 Q0 Q1 | I2 I3 Q2 Q3), see the kernel's B fragments
+                        const size_t at = (((((size_t)grp * n_q + q) * RD_CHAN_TERMS + tm) * RD_CHAN_RBG + rb) * 64 + lane) * 8 + 4 * (s4 / 2) + 2 * comp + (s4 % 2);
                         h->h_amat[at] = term[tm];
                     }
                 }
@@ -398,8 +432,8 @@ extern "C" int rd_chan_run(rd_chan *h, size_t n_out, void *dst_dev, size_t dst_s
     if (dst_stream_stride < 2 * n_out || (dst_stream_stride & 1))
         return rd_fail_msg(RD_ERR_ARG, "destination stride too small for n_out samples");
     const int T = h->t_pad, D = h->cfg.decim;
-    const size_t span = (size_t)(RD_CHAN_TT - 1) * D + T;
-    const size_t xs_bytes = (4 * span + 15) & ~(size_t)15;
+    const size_t span = (size_t)(RD_CHAN_TT - 1) * D + T + RD_CHAN_KC;
+    const size_t xs_bytes = (2 * span + 15 + 16) & ~(size_t)15;
     const size_t lds = xs_bytes;
     CHK(hipFuncSetAttribute((const void *)k_channelize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned gx = (unsigned)((n_out + RD_CHAN_TT - 1) / RD_CHAN_TT);
