@@ -919,6 +919,33 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         }
         if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane, halo_dma);
         if (!(stflags & 4)) __builtin_amdgcn_s_setprio(0);
+#ifdef RD_DIAG
+        // RD_K1_STFLAGS bits 24-27 = mode, bits 28-31 = n (diagnostic library): pacing experiments - s_sleep n behind the
+        // tile's loads for a SUBSET of the waves, so that the waves of a CU stop running through the tile in step
+        // (profiles/r03_pacing.txt).  1: odd waves (= SIMDs 1 and 3), 2: odd workgroups, 3: (wave ^ workgroup) odd,
+        // 5: wave w sleeps w n, 6: every wave (control), 7: waves 2 and 3, 8: wave 3 only
+        {
+            const uint32_t pm = (stflags >> 24) & 15u, pn = (stflags >> 28) & 15u;
+            bool sl = false;
+            if (pm == 1) sl = (wave & 1) != 0;
+            else if (pm == 2) sl = (blockIdx.x & 1) != 0;
+            else if (pm == 3) sl = ((wave ^ blockIdx.x) & 1) != 0;
+            else if (pm == 6) sl = true;
+            else if (pm == 7) sl = (wave & 2) != 0;
+            else if (pm == 8) sl = wave == 3;
+            if (sl) {
+                if (pn <= 1) __builtin_amdgcn_s_sleep(1);
+                else if (pn == 2) __builtin_amdgcn_s_sleep(2);
+                else if (pn <= 4) __builtin_amdgcn_s_sleep(4);
+                else __builtin_amdgcn_s_sleep(8);
+            }
+            if (pm == 5) {
+                if (wave == 1) __builtin_amdgcn_s_sleep(1);
+                else if (wave == 2) __builtin_amdgcn_s_sleep(2);
+                else if (wave == 3) __builtin_amdgcn_s_sleep(3);
+            }
+        }
+#endif
         if (STAMP) { sm_mark = rd_stamp(); sm_gap += sm_mark - sm_b; }
 
         uint32_t word = 0, fbytes = 0;
