@@ -692,7 +692,8 @@ static int batch_finish(rd_batch *b) {
             // guard list overflowed (degenerate input): re-evaluate every run exactly
             const rd_layout lay = batch_layout(b);
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
-            uint32_t cap = b->fix_cap;  // mark handled
+            // mark handled: neither this branch nor the self-fix one below may see the count again
+            uint32_t cap = b->self_run ? 0u : b->fix_cap;
             HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
             b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
             redo_search = true;
