@@ -91,6 +91,15 @@ const char *rd_last_error(void);
 int rd_device_count(void);
 /* Bind this process/thread's later calls to a device (hipSetDevice). */
 int rd_set_device(int device);
+/* Deadline of every host-side wait of this library (the polling waits for a run's results, a block's kernels, a
+ * device-to-host copy), in milliseconds; returns the previous value.  Default: RD_WAIT_TIMEOUT_MS from the
+ * environment, else 10000; ms < 0 restores that default.  A wait that passes its deadline returns RD_ERR_DEVICE
+ * ("timed out after ... waiting for ...") instead of spinning for ever, so that the caller's per-block try/except
+ * (/root/reference/src/rtldavis/worker.py:56-58: log, drop the block, continue) fires when a kernel never completes.
+ * The handle stays usable: a streaming handle drops the blocks in flight (waits for them again, discards their
+ * packets) at its next rd_demod_submit / rd_demod_block / rd_reset; a batch handle's next rd_batch_results waits again.
+ * ms = 0 makes every wait that is not satisfied at its first poll time out (test hook). */
+int rd_set_wait_timeout_ms(int ms);
 
 /* ---------------------------------------------------------------------------------------------
  * Streaming demodulator: one stream, one block per call, state carried across calls.

@@ -17,6 +17,7 @@
 
 #include <chrono>
 
+#include "rd_host.h"
 #include "rd_internal.h"
 #include "rd_math.h"
 
@@ -99,149 +100,47 @@ extern "C" int rd_set_device(int device) {
     return RD_OK;
 }
 
-// Wait for a stream by polling.  The runtime's blocking waits (hipStreamSynchronize, synchronous
-// hipMemcpy) were measured to add 10-20 ms of wake-up latency per call on this platform, an
-// order of magnitude more than a whole batch takes on the GPU.
-static int wait_event(hipEvent_t ev) {
+// Wait for an event / a stream by polling.  The runtime's blocking waits (hipStreamSynchronize, synchronous
+// hipMemcpy) were measured to add 10-20 ms of wake-up latency per call on this platform, an order of magnitude more
+// than a whole batch takes on the GPU.  Every wait has a deadline (rd_host.h: rd_waiter; RD_WAIT_TIMEOUT_MS, default
+// 10 s): a kernel that never completes must surface as RD_ERR_DEVICE so that the caller's "log, drop the block, go on"
+// (/root/reference/src/rtldavis/worker.py:56-58) can fire, not pin a core for ever.
+static int wait_event(hipEvent_t ev, const char *what) {
+    rd_waiter w(rd_wait_timeout_ms());
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return RD_OK;
         if (e != hipErrorNotReady) return fail(RD_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(e));
-        __builtin_ia32_pause();
+        if (!w.relax()) return fail(RD_ERR_DEVICE, "timed out after %.0f ms waiting for %s", w.waited_ms(), what);
     }
 }
 
-static int wait_stream(hipStream_t st) {
+static int wait_stream(hipStream_t st, const char *what) {
+    rd_waiter w(rd_wait_timeout_ms());
     for (;;) {
         const hipError_t e = hipStreamQuery(st);
         if (e == hipSuccess) return RD_OK;
         if (e != hipErrorNotReady) return fail(RD_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
-        __builtin_ia32_pause();
+        if (!w.relax()) return fail(RD_ERR_DEVICE, "timed out after %.0f ms waiting for %s", w.waited_ms(), what);
     }
 }
+
+extern "C" int rd_set_wait_timeout_ms(int ms) { return (int)rd_wait_timeout_set((double)ms); }
 
 // device -> host copy of n bytes on `st`, completed on return (polling wait)
 static int copy_d2h(void *dst, const void *src, size_t n, hipStream_t st) {
     if (n == 0) return RD_OK;
     HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st));
-    return wait_stream(st);
+    return wait_stream(st, "a device-to-host copy");
 }
 
-// ------------------------------------------------------------------------------------------
-// configuration (py:101-125)
-// ------------------------------------------------------------------------------------------
+// configuration (py:101-125) and the per-call order / dedupe of _slice (py:171-205): rd_host.cpp
 static int make_devcfg(const rd_config *c, rd_devcfg *d) {
-    if (!c) return fail(RD_ERR_ARG, "null config");
-    if (c->symbol_length < 1 || c->preamble_symbols < 1 || c->preamble_symbols > RD_MAX_PREAMBLE ||
-        c->packet_symbols < 1 || c->packet_symbols > 8 * RD_MAX_PKT_BYTES)
-        return fail(RD_ERR_ARG, "unsupported packet configuration");
-    if (c->packet_symbols < c->preamble_symbols)
-        return fail(RD_ERR_ARG, "packet_symbols < preamble_symbols is not supported");
-    if (c->block_size < 32 || c->block_size % 4)
-        return fail(RD_ERR_ARG, "block_size must be a multiple of 4 and >= 32 (rotate_fs4, py:46-49)");
-    d->S = c->symbol_length;
-    d->P = c->preamble_symbols;
-    d->K = c->packet_symbols;
-    d->B = c->block_size;
-    d->PL = c->preamble_symbols * c->symbol_length;
-    const long packet_length = (long)c->packet_symbols * c->symbol_length;
-    const long L = (packet_length / c->block_size + 2) * (long)c->block_size;
-    if (L > 0x3FFFFFFF) return fail(RD_ERR_ARG, "buffer_length too large");
-    d->L = (int32_t)L;
-    d->nbytes = (c->packet_symbols + 7) / 8;
-    d->fs = (double)c->bit_rate * (double)c->symbol_length;
-    d->pre_mask = 0;
-    for (int i = 0; i < c->preamble_symbols; i++) {
-        if (c->preamble[i] > 1) return fail(RD_ERR_ARG, "preamble symbols must be 0 or 1");
-        d->pre_mask |= (uint64_t)c->preamble[i] << i;
-    }
-    return RD_OK;
+    const char *why = "";
+    const int rc = rd_make_devcfg(c, d, &why);
+    return rc ? fail(rc, "%s", why) : RD_OK;
 }
-
-// Reference order inside one call: search is phase-major then ascending (py:175-186),
-// slice keeps the first occurrence of each byte string (py:203-205).
-// Records are ordered by (stream, call, index % S, index).  Small lists: std::sort.  Large
-// lists: the key is packed into 64 bits (when the field widths allow) and sorted with LSD
-// counting passes over (key, index) pairs - a comparison sort that moves 64-byte records costs
-// tens of milliseconds at 7e4 records.  `recs` may be pinned memory; output goes to `out`.
-struct rd_order_scratch {  // kept per handle: no allocation per call once warm
-    std::vector<uint32_t> idx, itmp, kept;
-    std::vector<uint64_t> key, ktmp;
-};
-
-// Fills sc.kept with the indices of the records to return, in order.
-static void order_and_dedupe(const rd_packet *recs, size_t n, int S, rd_order_scratch &sc) {
-    std::vector<uint32_t> &idx = sc.idx, &kept = sc.kept;
-    kept.clear();
-    idx.clear();
-    if (n == 0) return;
-    idx.reserve(n);
-    for (size_t i = 0; i < n; i++)
-        if (recs[i].stream >= 0) idx.push_back((uint32_t)i);  // stream < 0: match reported by no call
-    n = idx.size();
-    if (n == 0) return;
-    auto less = [&](uint32_t ia, uint32_t ib) {
-        const rd_packet &a = recs[ia], &b = recs[ib];
-        if (a.stream != b.stream) return a.stream < b.stream;
-        if (a.call != b.call) return a.call < b.call;
-        const int pa = a.index % S, pb = b.index % S;
-        if (pa != pb) return pa < pb;
-        return a.index < b.index;
-    };
-    if (n < 512) {
-        std::sort(idx.begin(), idx.end(), less);
-    } else {
-        // field widths
-        uint32_t max_stream = 0, max_call = 0, max_index = 0;
-        for (size_t i = 0; i < n; i++) {
-            const rd_packet &r = recs[idx[i]];
-            max_stream = std::max(max_stream, (uint32_t)r.stream);
-            max_call = std::max(max_call, (uint32_t)r.call);
-            max_index = std::max(max_index, (uint32_t)r.index);
-        }
-        auto bits_for = [](uint32_t v) { int b = 1; while (b < 32 && (v >> b)) b++; return b; };
-        const int bi = bits_for(max_index), bp = bits_for((uint32_t)(S - 1)), bc = bits_for(max_call),
-                  bs = bits_for(max_stream);
-        if (bi + bp + bc + bs <= 64) {
-            std::vector<uint64_t> &key = sc.key, &ktmp = sc.ktmp;
-            std::vector<uint32_t> &itmp = sc.itmp;
-            key.resize(n); ktmp.resize(n); itmp.resize(n);
-            for (size_t i = 0; i < n; i++) {
-                const rd_packet &r = recs[idx[i]];
-                key[i] = ((((uint64_t)(uint32_t)r.stream << bc | (uint32_t)r.call) << bp | (uint32_t)(r.index % S)) << bi) |
-                         (uint32_t)r.index;
-            }
-            // LSD passes of 12 bits (the bench shape's 36-bit key: three)
-            const int total_bits = bi + bp + bc + bs;
-            constexpr int DB = 12;
-            static thread_local uint32_t count[(1 << DB) + 1];
-            for (int shift = 0; shift < total_bits; shift += DB) {
-                memset(count, 0, sizeof count);
-                for (size_t i = 0; i < n; i++) count[((key[i] >> shift) & ((1u << DB) - 1)) + 1]++;
-                for (int d = 0; d < (1 << DB); d++) count[d + 1] += count[d];
-                for (size_t i = 0; i < n; i++) {
-                    const uint32_t pos = count[(key[i] >> shift) & ((1u << DB) - 1)]++;
-                    ktmp[pos] = key[i];
-                    itmp[pos] = idx[i];
-                }
-                key.swap(ktmp);
-                idx.swap(itmp);
-            }
-        } else {
-            std::sort(idx.begin(), idx.end(), less);
-        }
-    }
-    // per-call dedupe (py:203-205): the first occurrence of a byte string inside (stream, call) wins
-    kept.reserve(n);
-    size_t group = 0;
-    for (size_t i = 0; i < n; i++) {
-        const rd_packet &r = recs[idx[i]];
-        if (kept.empty() || r.stream != recs[kept.back()].stream || r.call != recs[kept.back()].call) group = kept.size();
-        bool dup = false;
-        for (size_t k = group; k < kept.size() && !dup; k++) dup = memcmp(recs[kept[k]].data, r.data, (size_t)r.nbytes) == 0;
-        if (!dup) kept.push_back(idx[i]);
-    }
-}
+static void order_and_dedupe(const rd_packet *recs, size_t n, int S, rd_order_scratch &sc) { rd_order_and_dedupe(recs, n, S, sc); }
 
 // ------------------------------------------------------------------------------------------
 // batch demodulator
@@ -488,12 +387,20 @@ extern "C" int rd_batch_input_ptr(rd_batch *b, void **dev_ptr, size_t *nbytes) {
     return RD_OK;
 }
 
+static int batch_flush(rd_batch *b);
+
 extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbytes) {
     if (!b || !iq_host) return fail(RD_ERR_ARG, "null argument");
     int rc = batch_alloc(b);
     if (rc) return rc;
     if (nbytes != b->iq_bytes) {
         return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu bytes, expected %zu", nbytes, b->iq_bytes);
+    }
+    if (b->ran && !b->fetched) {  // a run nobody fetched (e.g. its wait timed out) still reads the input
+        rc = batch_flush(b);
+        if (rc) return rc;
+        rc = wait_event(b->done, "the previous run before an upload");
+        if (rc) return rc;
     }
     HIPCHK(hipMemcpy(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice));
     b->ord_off = false;  // a new input: the ordered tail gets its chance again
@@ -616,15 +523,18 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     int rc = batch_alloc(b);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    b->stream = st;
     const rd_layout lay = batch_layout(b);
     // the previous run's readback of d_cnt / d_recs must be over before they are rewritten: the host
     // has already waited for it if the results were fetched (the normal order), else the stream waits
     if (b->ran && !b->fetched) {
-        rc = batch_flush(b);  // (a pipelined run nobody adopted: its readback is not even enqueued yet)
+        // (a pipelined run nobody adopted: its readback is not even enqueued yet.  b->stream is still the stream THAT
+        // run was launched on - the key of its g_tail entry and where its completion event belongs - and `done`, recorded
+        // behind its readback, orders this run's kernels on `st` after it whichever stream that was)
+        rc = batch_flush(b);
         if (rc) return rc;
         HIPCHK(hipStreamWaitEvent(st, b->done, 0));
     }
+    b->stream = st;
     b->fetched = false;
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;
@@ -658,7 +568,11 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
         if (b->fast_ok) honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit, extra, b->last_launch);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
-        if (adopt && (rc = batch_adopt(b->device, st, b->ev[1]))) return rc;
+        if (adopt) {  // (an event of THIS run: b->ev is null - or a finished run's - when the handle is untimed)
+            hipEvent_t carrier = b->timing ? b->ev[1] : b->kfirst;
+            if (!b->timing) HIPCHK(hipEventRecord(carrier, st));
+            if ((rc = batch_adopt(b->device, st, carrier))) return rc;
+        }
     }
     // self-fix: the demod kernel's waves have patched their own words; the search kernel clears the next counter set
     b->second_pass = false;
@@ -683,7 +597,7 @@ static int batch_finish(rd_batch *b) {
     }
     for (int attempt = 0; attempt < 8; attempt++) {
         const double ta = now_ms();
-        int wrc = wait_event(b->done);
+        int wrc = wait_event(b->done, "the batch run's results");
         if (wrc) return wrc;
         memcpy(b->h_cnt, b->h_cnt_pin, sizeof b->h_cnt);
         if (dbg_host()) fprintf(stderr, "[rd] finish: wait %.3f ms\n", now_ms() - ta);
@@ -1019,6 +933,8 @@ struct rd_demod {
     bool one_ok = false;            // the configuration is one k_stream_block is built for (and RD_STREAM_IMPL != legacy)
     uint32_t seq = 0;               // blocks sent through k_stream_block
     std::vector<rd_packet> gather;  // records of a one-launch block, streams one after the other
+    int stale = 0;                  // blocks in flight whose fetch timed out: dropped (waited for, results discarded) by
+                                    // the next submit / reset - the caller has already been told (worker.py:56-58)
 };
 
 extern "C" int rd_create_multi(const rd_config *cfg, int n_streams, rd_demod **out) {
@@ -1114,8 +1030,53 @@ extern "C" void rd_destroy(rd_demod *h) {
     delete h;
 }
 
+// Wait (polling, with the deadline of every host wait) until the block in `sl` has completed.
+static int demod_wait_slot(rd_demod *h, rd_slot &sl) {
+    if (!sl.one) return wait_event(sl.e_done, "the block's kernels");
+    // one-launch block: the streams' sequence numbers in pinned memory (an event query costs microseconds; a kernel
+    // that died would never write them, so the stream is asked now and then)
+    const size_t NS = (size_t)h->NS;
+    volatile uint32_t *flag = sl.h_sb + NS;
+    rd_waiter w(rd_wait_timeout_ms());
+    uint32_t spins = 0;
+    for (size_t s = 0; s < NS; s++) {
+        while (flag[s] != sl.seq) {
+            if (!w.relax())
+                return fail(RD_ERR_DEVICE, "timed out after %.0f ms waiting for the block's kernel (stream %zu of %zu)",
+                            w.waited_ms(), s, NS);
+            if ((++spins & 0xFFF) == 0xFFF || w.polls >= 1024) {  // (>= 1024 polls: past the 50 us of spinning)
+                const hipError_t e = hipStreamQuery(h->st);
+                if (e != hipSuccess && e != hipErrorNotReady)
+                    return fail(RD_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
+                if (e == hipSuccess && flag[s] != sl.seq)
+                    return fail(RD_ERR_DEVICE, "the block's kernel finished without reporting stream %zu", s);
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return RD_OK;
+}
+
+// Blocks whose fetch timed out are still in flight: wait for them (deadline again) and discard what they found - the
+// streams' state (ring, window) has advanced by them as the reference's would have, only their packets are lost.
+static int demod_drop_stale(rd_demod *h) {
+    while (h->stale > 0 && h->nflight > 0) {
+        int rc = demod_wait_slot(h, h->slot[h->head]);
+        if (rc) return rc;
+        h->head ^= 1;
+        h->nflight--;
+        h->stale--;
+    }
+    h->stale = 0;
+    return RD_OK;
+}
+
 // every block in flight has been fetched (state accessors and reset need a quiet handle)
-static int demod_quiet(const rd_demod *h) {
+static int demod_quiet(rd_demod *h) {
+    if (h->stale) {
+        int rc = demod_drop_stale(h);
+        if (rc) return rc;
+    }
     if (h->nflight) return fail(RD_ERR_STATE, "%d block(s) in flight: rd_demod_fetch them first", h->nflight);
     return RD_OK;
 }
@@ -1124,17 +1085,18 @@ extern "C" int rd_reset(rd_demod *h) {
     if (!h) return fail(RD_ERR_ARG, "null handle");
     if (h->dev_ready) {
         // blocks still in flight are dropped: wait for them, then clear
+        // (on a timeout the handle is left as it was: reset() may be called again once the device has caught up)
         for (int i = 0; i < h->nflight; i++) {
-            rd_slot &sl = h->slot[(h->head + i) & 1];
-            int rc = sl.one ? wait_stream(h->st) : wait_event(sl.e_done);
+            int rc = demod_wait_slot(h, h->slot[(h->head + i) & 1]);
             if (rc) return rc;
         }
         const size_t L = (size_t)h->dc.L;
         for (int i = 0; i < 2; i++)
             HIPCHK(hipMemsetAsync(h->d_win[i], 0, (size_t)h->NS * ((L + 31) / 32) * 4, h->st));
-        int rc = wait_stream(h->st);
+        int rc = wait_stream(h->st, "reset()'s clears");
         if (rc) return rc;
     }
+    h->stale = 0;
     h->nflight = 0;
     h->head = 0;
     h->seen = 0;
@@ -1191,6 +1153,7 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
     const size_t bw = (B + 31) / 32, lw = (L + 31) / 32;
     int rc = demod_alloc(h);
     if (rc) return rc;
+    if (h->stale && (rc = demod_drop_stale(h))) return rc;
     if (h->nflight >= 2) return fail(RD_ERR_STATE, "two blocks in flight: rd_demod_fetch one first");
     rd_slot &sl = h->slot[(h->head + h->nflight) & 1];
     hipStream_t st = h->st;
@@ -1299,24 +1262,16 @@ static int demod_give(rd_demod *h, rd_packet *out, int cap, int *n) {
 static int demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {
     if (h->nflight == 0) return fail(RD_ERR_STATE, "no block in flight");
     rd_slot &sl = h->slot[h->head];
-    if (sl.one) {
-        // poll the streams' sequence numbers in pinned memory (an event query costs microseconds; a kernel that died
-        // would never write them, so the stream is asked now and then)
-        const size_t NS = (size_t)h->NS, per = (size_t)h->dc.B + 1;
-        volatile uint32_t *flag = sl.h_sb + NS;
-        for (size_t s = 0; s < NS; s++) {
-            for (uint32_t spins = 0; flag[s] != sl.seq; spins++) {
-                __builtin_ia32_pause();
-                if ((spins & 0xFFFF) == 0xFFFF) {
-                    const hipError_t e = hipStreamQuery(h->st);
-                    if (e != hipSuccess && e != hipErrorNotReady)
-                        return fail(RD_ERR_DEVICE, "hipStreamQuery: %s", hipGetErrorString(e));
-                    if (e == hipSuccess && flag[s] != sl.seq)
-                        return fail(RD_ERR_DEVICE, "the block's kernel finished without reporting stream %zu", s);
-                }
-            }
+    if (h->stale) return fail(RD_ERR_STATE, "the blocks in flight were given up on (their fetch timed out): submit the next block or reset()");
+    {
+        int rc = demod_wait_slot(h, sl);
+        if (rc) {  // every block in flight is dropped: the next submit / reset waits for them and discards their packets
+            if (rc == RD_ERR_DEVICE) h->stale = h->nflight;
+            return rc;
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (sl.one) {
+        const size_t NS = (size_t)h->NS, per = (size_t)h->dc.B + 1;
         h->head ^= 1;
         h->nflight--;
         h->gather.clear();
@@ -1329,8 +1284,6 @@ static int demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {
         for (uint32_t k : h->order.kept) h->last.push_back(h->gather[k]);
         return demod_give(h, out, cap, n);
     }
-    int rc = wait_event(sl.e_done);
-    if (rc) return rc;
     h->head ^= 1;
     h->nflight--;
     const uint32_t nrec = std::min(sl.h_cnt[RD_CNT_MATCH], h->match_cap);  // one record per match (no call overlap here)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/rtldavis_hip.h"
+#include "rd_host.h"
 
 // counters[] slots (device uint32)
 // FIX: flagged runs; MATCH: preamble matches (= primary records); REC: second records of
@@ -53,11 +54,7 @@ struct rd_layout {
     size_t bits_stride;       // words
 };
 
-struct rd_devcfg {
-    int32_t S, P, K, B, L, PL, nbytes;  // symbol_length, preamble/packet symbols, block, buffer, preamble_length
-    uint64_t pre_mask;                  // bit m = preamble symbol m
-    double fs;                          // sample rate = bit_rate * symbol_length (protocol.py:309)
-};
+// rd_devcfg: rd_host.h (the pure-host translation unit shares it)
 
 struct rd_match {
     int32_t stream;

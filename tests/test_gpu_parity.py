@@ -1022,3 +1022,138 @@ def test_ordered_tail_falls_back_when_a_stream_overflows_its_bucket(dsp, batchmo
     res = bd.packets()
     for i, seed in enumerate(seeds):
         assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+
+
+# ---------------------------------------------------------------- round 4: host waits, stream hand-over
+def _hip_stream():
+    """A second hipStream_t (integer handle) from the HIP runtime the library already loaded."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    return st.value
+
+
+@pytest.mark.gpu
+def test_host_wait_deadline_drops_the_block_and_goes_on(dsp, batchmod, golden_streams):
+    """Every host wait has a deadline (rd_set_wait_timeout_ms / RD_WAIT_TIMEOUT_MS): a wait that passes it raises
+    HipError instead of spinning for ever, so that the worker's "log, drop the block, continue"
+    (/root/reference/src/rtldavis/worker.py:56-58) fires.  Nothing is made to hang: with the deadline at 0 an ordinary
+    block times out.  The dropped block's packets are lost, the stream's state is not: every later call equals the
+    fixture; so does a whole stream after reset(); a batch run whose wait timed out is fetched by the next call."""
+    from rtldavis_amd import _lib
+    L = _lib.lib()
+    B = 8192
+    raw = synth.synth_stream(0)
+    want = dense_calls(golden_streams["0"]["calls"], synth.BLOCKS_PER_STREAM)
+    for make, feed in ((lambda: dsp.Demodulator(prod_cfg(dsp)), lambda d, blk: d.demodulate(blk)),):
+        dem = make()
+        calls = []
+        for b in range(synth.BLOCKS_PER_STREAM):
+            blk = raw[2 * B * b: 2 * B * (b + 1)]
+            if b == 7:  # (a call without packets in the fixture)
+                assert want[b] == []
+                prev = L.rd_set_wait_timeout_ms(0)
+                try:
+                    with pytest.raises(_lib.HipError, match="timed out"):
+                        feed(dem, blk)
+                    with pytest.raises(RuntimeError):   # its packets are gone: nothing to fetch
+                        dem.fetch()
+                finally:
+                    assert L.rd_set_wait_timeout_ms(-1) == 0
+                assert prev > 0
+                calls.append([])
+                continue
+            calls.append(feed(dem, blk))
+        assert_calls_equal(calls, want)
+        # a timed-out fetch of a submitted block, then reset(): waits for the block that was given up on, clears
+        dem.submit(raw[: 2 * B])
+        L.rd_set_wait_timeout_ms(0)
+        try:
+            with pytest.raises(_lib.HipError, match="timed out"):
+                dem.fetch()
+        finally:
+            L.rd_set_wait_timeout_ms(-1)
+        dem.reset()
+        assert_calls_equal(run_streaming(dem, raw), want)
+    # batch handle: the wait for a run's results
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), 2, synth.BLOCKS_PER_STREAM)
+    bd.upload(synth.synth_streams([0, 1]))
+    bd.run()
+    bd.packets()          # (first run: buffers and kernels warm)
+    L.rd_set_wait_timeout_ms(0)
+    try:
+        bd.run()
+        with pytest.raises(_lib.HipError, match="timed out"):
+            bd.results()
+    finally:
+        L.rd_set_wait_timeout_ms(-1)
+    res = bd.packets()    # the run is still there to be fetched
+    for i, seed in enumerate((0, 1)):
+        assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+    bd.upload(synth.synth_streams([2, 3]))   # upload -> run -> results goes on as before
+    res = bd.demodulate(synth.synth_streams([2, 3]))
+    for i, seed in enumerate((2, 3)):
+        assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+
+
+@pytest.mark.gpu
+def test_pipelined_run_adopted_by_an_untimed_handle_without_the_fast_kernel(dsp, batchmod, golden_streams):
+    """ADVICE r3 (rd_batch_run, third branch): a pipelined run waiting on a stream is adopted by the next run launched
+    there; when that run belongs to an untimed handle whose streams are not 16-byte multiples (no fused demod kernel,
+    no dispatch event) the carrier must be an event of THAT run.  A's packets = the fixtures, B's = the C oracle."""
+    from oracle import c_oracle as CO
+    seeds = [0, 1, 2]
+    a = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    a.upload(synth.synth_streams(seeds))
+    a.set_pipelined(True)
+    rng = np.random.default_rng(11)
+    Bb, nb, ns = 36, 70, 3   # 2 * 36 * 70 bytes per stream = 5040: not a multiple of 16
+    raw_b = rng.integers(0, 256, size=(ns, 2 * Bb * nb), dtype=np.uint8)
+    b = batchmod.BatchDemodulator(prod_cfg(dsp, block_size=Bb), ns, nb)
+    b.upload(raw_b)
+    want_b, _ = CO.demod_batch(raw_b, CO.make_cfg(block_size=Bb), threads=2, want_bits=True)
+    for _ in range(3):
+        a.run()
+        b.run()          # adopts a's run
+        res_a = a.packets()
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res_a[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+        res_b = b.packets()
+        for i in range(ns):
+            got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res_b[i]) for p in ps]
+            assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want_b[i]]
+
+
+@pytest.mark.gpu
+def test_pipelined_handle_rerun_on_another_stream(dsp, batchmod, golden_streams):
+    """ADVICE r3 (rd_batch_run): a pipelined run nobody fetched, then the same handle run again on ANOTHER stream: the
+    first run is flushed on the stream it was launched on (its completion event there, its g_tail entry removed), the
+    second waits for it; then a third handle launched on the first stream must not adopt anything stale, and destroying
+    the handles leaves nothing behind.  Results = the fixtures every time."""
+    seeds = [4, 5, 6, 7]
+    st2 = _hip_stream()
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    bd.upload(synth.synth_streams(seeds))
+    bd.set_pipelined(True)
+    other = batchmod.BatchDemodulator(prod_cfg(dsp), 2, synth.BLOCKS_PER_STREAM)
+    other.upload(synth.synth_streams([0, 1]))
+
+    def check(h, sd):
+        res = h.packets()
+        for i, seed in enumerate(sd):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+
+    for _ in range(3):
+        bd.run(0)        # deferred on the null stream
+        bd.run(st2)      # not fetched: flushed where it was launched, then this run on st2
+        other.run(0)     # the null stream holds no waiting run any more
+        check(other, [0, 1])
+        check(bd, seeds)
+        bd.run(st2)
+        bd.run(0)
+        check(bd, seeds)
+    bd.run(st2)
+    bd.close()           # destroyed with a run waiting on st2
+    other.run(st2)
+    check(other, [0, 1])
