@@ -80,6 +80,9 @@ def parse_args():
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "
                          "synthetic 26.88 MS/s capture (channelizer + demodulator), N = 1 only")
+    ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",
+                    help="N > 1: backend of the barrier / max-over-ranks time (no data-path collective exists). auto = nccl (RCCL), "
+                         "falling back to gloo in the same process when its initialisation fails")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="N > 1 dry run on a one-GPU box: all ranks on cuda:0, gloo barrier (not a measurement)")
     return ap.parse_args()
@@ -310,12 +313,33 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dist_backend, dist_note = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
+        want = "gloo" if rehearse else args.dist_backend
+        if want in ("auto", "nccl"):
+            # The path shards without any exchange: torch.distributed only carries the barrier, the
+            # max-over-ranks time and the gathered per-GPU lines.  RCCL is the contract's backend; a run that needs no
+            # collective must not die because RCCL cannot come up (IPC mode, a busy fabric), so its failure - at
+            # initialisation or at the first barrier - falls back to gloo in this same process (no re-exec).
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+                torch.cuda.synchronize()
+                dist_backend = "nccl"
+            except Exception as e:  # noqa: BLE001 - whatever RCCL raises
+                if want == "nccl":
+                    raise
+                dist_note = f"nccl failed ({type(e).__name__}: {str(e)[:120]}): gloo"
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+        if dist_backend is None:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist_backend = "gloo"
+    on_cpu = dist_backend != "nccl"   # where the tensors of the (two) scalar reductions live
 
     from rtldavis_amd import _lib, batch, dsp, synth
 
@@ -423,8 +447,9 @@ def main():
     tms = [x.timing() for x in bds]  # mean kernel durations (HIP events on the launch stream)
     assert sum(t["runs"] for t in tms) == args.steps
     tm = {k: sum(t[k] * t["runs"] for t in tms) / args.steps for k in tms[0] if k != "runs"}
+    own_elapsed = elapsed
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -465,12 +490,29 @@ def main():
             ok &= hashlib.sha256(bd.bits(s).tobytes()).hexdigest() == gold[str(s % nu)]["bits_sha256"]
         verified = bool(ok)
         if world > 1:  # every rank must agree
-            vt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            vt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
             dist.all_reduce(vt, op=dist.ReduceOp.MIN)
             verified = bool(vt.item() > 0.5)
+        own_verified = bool(ok)
         if not verified:
             raise SystemExit(f"bench.py: GPU output differs from the reference fixtures (rank {rank}: "
                              f"{'ok' if ok else 'MISMATCH'}) - result invalid")
+    else:
+        own_verified = None
+
+    # BASELINE configs[4]: per-GPU MSamples/s next to the aggregate - every rank's own clock, kernel time and
+    # verification, gathered on rank 0 (a straggler GPU shows here; MAX(elapsed) alone would hide which one it is)
+    per_gpu = None
+    if world > 1:
+        dm_own = float(tm["demod_ms"])
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank) + f" (cuda:{local_rank})",
+                "value": round(n_streams * n_samples * args.steps / own_elapsed / 1e6, 1),
+                "ms_per_step": round(1e3 * own_elapsed / args.steps, 4), "kernel_ms": round(dm_own, 4),
+                "roofline_frac": round(n_streams * n_samples * 2 / (dm_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "verified": own_verified}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_gpu = sorted(gathered, key=lambda d: d["rank"])
 
     # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 runs
     # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel's INSTRUCTIONS as
@@ -553,6 +595,9 @@ def main():
             out["roofline"]["traffic_source"] = traffic_source
         if sustained:
             out["sustained"] = sustained
+        if per_gpu is not None:
+            out["per_gpu"] = per_gpu
+            out["dist_backend"] = dist_backend + (f" ({dist_note})" if dist_note else "")
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             # the GPU figures are complete here: show them (stderr) before the CPU legs take their ~25 s; the ONE JSON
             # line on stdout follows with `cpu_baseline` in it

@@ -208,6 +208,7 @@ int rd_batch_set_pipelined(rd_batch *b, int enabled);
 #define RD_FORM_SELF_FIX 2u       /* RD_FIXUP_IMPL=self: no k_fixup launch */
 #define RD_FORM_FUSED_SEARCH 4u   /* RD_SEARCH_IMPL=fused: preamble test inside the demod kernel */
 #define RD_FORM_SECOND_PASS 8u    /* a list or bucket overflowed: search and slice ran a second time, in full */
+#define RD_FORM_ONE_LAUNCH_TAIL 16u /* everything behind the demod kernel ran as ONE launch (k_tail; implies ORDERED_TAIL) */
 int rd_batch_last_run_forms(rd_batch *b, uint32_t *forms);
 /* Counters of the last run: 32-sample runs with at least one 8-sample group re-evaluated
  * exactly (guard band), raw preamble matches. */

@@ -189,6 +189,17 @@ struct rd_batch {
     rd_ord_bufs ord;
     bool ord_ok = false, ord_run = false, ord_off = false;
     uint32_t bucket_limit = RD_BUCKET;
+    // The one-launch tail (round 4, rd_launch_tail_fused: k_tail): fix-up, search, slice with order and dedupe, RSSI and
+    // the final records in ONE kernel, a workgroup per RD_FT_STREAMS streams; the demod kernel's waves put their fix-up
+    // entries into per-group buckets (RD_DEMOD_FIX_BUCKETS) and no k_fixup is launched.  ft_ok: the buffers exist
+    // (Davis shape, RD_TAIL_IMPL unset); ft_run: the run in flight used it; its overflows (a stream's match list, a
+    // group's fix-up bucket) send this input through the separate kernels (ord_off, as for the ordered tail) and the
+    // next upload gets lists twice as long.
+    rd_ft_bufs ft;
+    bool ft_ok = false, ft_run = false;
+    uint32_t ft_seq = 0, ft_limit = 0;   // ft_limit: test hook RD_TEST_BUCKET_CAP (0: none)
+    bool ft_sticky = false;              // an input overflowed the longest match lists: uploads no longer re-enable k_tail
+    size_t ft_cnt_off = 0;               // the groups' fix-up counters inside a counter set (words)
     size_t cnt_stride = RD_CNT_TOTAL;  // words per counter set (the per-stream match counters live behind the counters)
     // Pipelined completion (rd_batch_set_pipelined): the run's last kernel carries no event; the readback is hung on
     // the stop event of the NEXT demod kernel launched on the same stream (any handle's), see batch_adopt below.
@@ -287,13 +298,18 @@ static int batch_alloc(rd_batch *b) {
     // ordered tail: Davis shape only (the kernels are compiled for it); RD_TAIL_IMPL=legacy switches it off (A/B),
     // RD_TEST_BUCKET_CAP makes the buckets small so that the fallback runs on ordinary inputs (test hook)
     {
+        // RD_TAIL_IMPL: unset = the one-launch tail (k_tail); "ordered" = round 3's four launches with the order and
+        // dedupe on the device; "legacy" = the unordered kernels + host ordering
         const char *ti = getenv("RD_TAIL_IMPL");
         const bool legacy = (ti && ti[0] == 'l') || getenv("RD_SLICE_IMPL");  // (an explicit slice form means the unordered kernels)
         b->ord_ok = !legacy && b->fast_ok && b->dc.S == 14 && b->dc.P == 16 && b->dc.K == 80 && b->dc.pre_mask == 0x91D3ull &&
                     b->n_samples < (1l << 30) && b->dc.B < (1 << 24);
+        b->ft_ok = b->ord_ok && !(ti && ti[0] == 'o') && b->bits_stride % 4 == 0 && b->dc.L >= b->dc.B &&
+                   (long)(b->n_blocks + 1) * b->dc.B - b->dc.L >= 0 &&   // (a batch shorter than a packet has no position to report)
+                   ((long)(b->n_blocks + 1) * b->dc.B - b->dc.L) / 32 + 16 <= (long)b->bits_stride;
         if (const char *e = getenv("RD_TEST_BUCKET_CAP")) {
             const long v = atol(e);
-            if (v >= 1 && v < RD_BUCKET) b->bucket_limit = (uint32_t)v;
+            if (v >= 1 && v < RD_BUCKET) { b->bucket_limit = (uint32_t)v; b->ft_limit = (uint32_t)v; }
         }
     }
     {   // RD_FIXUP_IMPL=self: self-fix - the demod kernel's waves re-evaluate the groups they flagged themselves and no
@@ -303,12 +319,31 @@ static int batch_alloc(rd_batch *b) {
         // happens on ordinary inputs (test hook)
         const char *fi = getenv("RD_FIXUP_IMPL");
         b->self_fix = b->fast_ok && fi && fi[0] == 's';
+        if (b->self_fix) b->ft_ok = false;  // (the opt-in forms of round 3 feed the four-launch tail)
+        if (const char *si = getenv("RD_SEARCH_IMPL")) if (si[0] == 'f') b->ft_ok = false;
         if (const char *e = getenv("RD_TEST_SELF_PEND")) {
             const long v = atol(e);
             if (v >= 1 && v < 255) b->self_pend_limit = (uint32_t)v;
         }
     }
     b->cnt_stride = RD_CNT_TOTAL + (b->ord_ok ? (((size_t)b->n_streams + 3) & ~(size_t)3) : 0);
+    if (b->ft_ok) {  // the groups' fix-up counters live behind the per-stream match counters: cleared with the set
+        const size_t groups = ((size_t)b->n_streams + RD_FT_STREAMS - 1) / RD_FT_STREAMS;
+        b->ft_cnt_off = b->cnt_stride;
+        b->cnt_stride += (groups + 3) & ~(size_t)3;
+        // a group's bucket: the first group of every chunk of tiles (chunks of four tiles at the least) and the first
+        // run of each of its streams are always listed; twice that, plus room for the groups inside the guard band
+        const uint64_t tps = ((uint64_t)b->n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
+        b->ft.fix_bcap = (uint32_t)std::min<uint64_t>((2 * RD_FT_STREAMS * (tps / 4 + 8) + 63) & ~63ull, 1u << 20);
+        if (const char *e = getenv("RD_TEST_FIX_BCAP")) {  // test hook: small buckets, so that their overflow path runs on ordinary inputs
+            const long v = atol(e);
+            if (v >= 1 && v < (long)b->ft.fix_bcap) b->ft.fix_bcap = (uint32_t)v;
+        }
+        b->ft.bcap = rd_ord_bucket_cap(b->n_samples);
+        HIPCHK(hipMalloc(&b->ft.fixb, groups * b->ft.fix_bcap * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&b->ft.gstate, 3 * groups * sizeof(uint32_t)));
+        HIPCHK(hipMemset(b->ft.gstate, 0, 3 * groups * sizeof(uint32_t)));
+    }
     HIPCHK(hipMalloc(&b->d_cnt, 2 * b->cnt_stride * sizeof(uint32_t)));
     HIPCHK(hipMemset(b->d_cnt, 0, 2 * b->cnt_stride * sizeof(uint32_t)));
     if (b->ord_ok) {
@@ -368,6 +403,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
         hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.wgtot); hipFree(b->d_extra); hipFree(b->d_wmatch); hipFree(b->d_wcount);
+        hipFree(b->ft.fixb); hipFree(b->ft.gstate);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
@@ -403,7 +439,7 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
         if (rc) return rc;
     }
     HIPCHK(hipMemcpy(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice));
-    b->ord_off = false;  // a new input: the ordered tail gets its chance again
+    if (!b->ft_sticky) b->ord_off = false;  // a new input: the tail with the order on the device gets its chance again
     return RD_OK;
 }
 
@@ -472,7 +508,17 @@ static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = fals
     hipEvent_t last = defer ? nullptr : b->run_timing ? b->ev[4] : b->kdone;
     if (b->run_timing && may_defer) b->ev_end.push_back(defer ? 0 : 1);
     b->ord_run = false;
-    if (b->ord_ok && !b->ord_off && !(b->run_timing && b->run_detail)) {
+    if (b->ft_run && may_defer) {  // the run's first pass: everything behind the demod kernel in one launch
+        rd_ft_bufs fb = b->ft;
+        fb.fixcnt = batch_cnt(b) + b->ft_cnt_off;
+        b->ft_seq = b->ft_seq % 4095u + 1u;
+        const int ok = rd_launch_tail_fused(lay, b->dc, b->n_blocks, B - L, (long)(b->n_blocks + 1) * B - L, fb,
+                                            b->ft_limit ? b->ft_limit : fb.bcap, b->ft_seq, 0, b->d_recs, b->rec_cap, batch_cnt(b), st,
+                                            last_on_slice ? last : nullptr, zero_next, (uint32_t)b->cnt_stride);
+        if (!ok) return fail(RD_ERR_STATE, "the one-launch tail refused a shape its buffers were allocated for");
+        b->ord_run = true;   // (the records are final, as the ordered tail's)
+        b->dense = 1;
+    } else if (b->ord_ok && !b->ord_off && !(b->run_timing && b->run_detail)) {
         rd_ord_bufs ob = b->ord;
         ob.scount = batch_cnt(b) + RD_CNT_TOTAL;
         // fused search: on the run's first pass the demod kernel has filled the buckets and k_search_rem adds what it
@@ -554,19 +600,24 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     const bool adopt = batch_stream_has_tail(b->device, st);
     // (the fused search feeds the ordered tail's buckets: only when that tail is going to run)
     const bool want_fused = b->fused && b->ord_ok && !b->ord_off && !(b->timing && b->timing_detail) && !b->parse;
-    const uint32_t dflags = (b->self_fix ? RD_DEMOD_SELF_FIX : 0u) | (want_fused ? RD_DEMOD_FUSED_SEARCH : 0u);
+    // the one-launch tail: the fix-up entries go to its workgroups' buckets
+    const bool want_ft = b->ft_ok && b->fast_ok && !b->ord_off && !(b->timing && b->timing_detail);
+    const uint32_t dflags = (b->self_fix ? RD_DEMOD_SELF_FIX : 0u) | (want_fused ? RD_DEMOD_FUSED_SEARCH : 0u) |
+                            (want_ft ? RD_DEMOD_FIX_BUCKETS : 0u);
     const rd_mf_extra *extra = want_fused ? b->d_extra + b->cnt_set : nullptr;
+    uint32_t *fixl = want_ft ? b->ft.fixb : b->d_fix, *bcnt = want_ft ? cnt + b->ft_cnt_off : nullptr;
+    const uint32_t fixc = want_ft ? b->ft.fix_bcap : b->fix_cap;
     uint32_t honoured = 0;
     if (b->timing && b->fast_ok) {
         // the demod kernel's dispatch carries its own start / stop events (no marker packets)
-        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit, extra, b->last_launch);
+        honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit, extra, b->last_launch, bcnt);
         if (adopt && (rc = batch_adopt(b->device, st, b->ev[1]))) return rc;
     } else if (b->fast_ok && adopt) {
-        honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit, extra, b->last_launch);
+        honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit, extra, b->last_launch, bcnt);
         if ((rc = batch_adopt(b->device, st, b->kfirst))) return rc;
     } else {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
-        if (b->fast_ok) honoured = rd_launch_demod(lay, b->d_fix, b->fix_cap, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit, extra, b->last_launch);
+        if (b->fast_ok) honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit, extra, b->last_launch, bcnt);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
         if (adopt) {  // (an event of THIS run: b->ev is null - or a finished run's - when the handle is untimed)
             hipEvent_t carrier = b->timing ? b->ev[1] : b->kfirst;
@@ -578,10 +629,11 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     b->second_pass = false;
     b->self_run = b->fast_ok && (honoured & RD_DEMOD_SELF_FIX);
     b->fused_run = b->fast_ok && (honoured & RD_DEMOD_FUSED_SEARCH);
-    if (!b->self_run)
+    b->ft_run = b->fast_ok && (honoured & RD_DEMOD_FIX_BUCKETS);   // (k_tail does the fix-up and clears the next counter set)
+    if (!b->self_run && !b->ft_run)
         rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
-    rc = batch_search_slice(b, st, true, b->self_run ? cnt_next : nullptr);
+    rc = batch_search_slice(b, st, true, (b->self_run || b->ft_run) ? cnt_next : nullptr);
     if (rc) return rc;
     b->ran = true;
     return RD_OK;
@@ -602,7 +654,24 @@ static int batch_finish(rd_batch *b) {
         memcpy(b->h_cnt, b->h_cnt_pin, sizeof b->h_cnt);
         if (dbg_host()) fprintf(stderr, "[rd] finish: wait %.3f ms\n", now_ms() - ta);
         bool redo_search = false;
-        if (b->fast_ok && b->h_cnt[RD_CNT_FIX] > b->fix_cap) {
+        if (b->ft_run && !b->second_pass && (b->h_cnt[RD_CNT_OVF] & (8u | 16u))) {
+            // a group's fix-up bucket overflowed (quiet or degenerate input), or a workgroup gave up waiting for the
+            // groups in front of it: every run is re-evaluated exactly, then the separate kernels
+            const rd_layout lay = batch_layout(b);
+            rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
+            b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
+            b->ord_off = true;
+            b->h_cnt[RD_CNT_OVF] = 0;
+            b->h_cnt[RD_CNT_FIX] = 0;
+            redo_search = true;
+        } else if (b->ft_run && !b->second_pass && (b->h_cnt[RD_CNT_OVF] & 1u)) {
+            // a stream with more matches than its list in LDS holds: this input takes the separate kernels, the next
+            // upload gets lists twice as long
+            if (!b->ft_limit && b->ft.bcap < RD_BUCKET_MAX) b->ft.bcap = std::min<uint32_t>(2 * b->ft.bcap, RD_BUCKET_MAX);
+            else if (!b->ft_limit) b->ft_sticky = true;  // (the longest lists there are: inputs like this one keep the separate kernels)
+        }
+        if (redo_search) {
+        } else if (b->fast_ok && !b->ft_run && b->h_cnt[RD_CNT_FIX] > b->fix_cap) {
             // guard list overflowed (degenerate input): re-evaluate every run exactly
             const rd_layout lay = batch_layout(b);
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
@@ -623,6 +692,7 @@ static int batch_finish(rd_batch *b) {
         } else if (attempt == 0) {
             b->last_fix = (uint64_t)b->h_cnt[RD_CNT_FIX] + (b->self_run ? b->h_cnt[RD_CNT_SELF] : 0u);
         }
+        if (redo_search && b->ord_off) b->ord_run = false;  // (the bucket-overflow branch above: not the record-overflow one below)
         if (b->ord_run && b->h_cnt[RD_CNT_OVF]) {
             // a stream with more matches than its bucket holds (or more records than the list): this input goes
             // through the unordered kernels and the host-side ordering, now and until the next upload
@@ -666,7 +736,7 @@ static int batch_finish(rd_batch *b) {
             b->fetched = true;
             return RD_OK;
         }
-        const uint32_t zero[4] = {0, 0, 0, 0};  // matches, boundary records, (unused), parsed
+        const uint32_t zero[5] = {0, 0, 0, 0, 0};  // matches, boundary records, tasks, parsed, overflow flags
         HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
         // (the ordered tail's per-stream match counts hold the first pass's matches: its search starts from zero again)
         if (b->ord_ok && b->cnt_stride > RD_CNT_TOTAL)
@@ -869,7 +939,7 @@ extern "C" int rd_batch_last_run_forms(rd_batch *b, uint32_t *forms) {
     if (!b || !forms) return fail(RD_ERR_ARG, "null argument");
     int rc = batch_finish(b);
     if (rc) return rc;
-    *forms = (b->ord_run ? RD_FORM_ORDERED_TAIL : 0u) | (b->self_run ? RD_FORM_SELF_FIX : 0u) |
+    *forms = (b->ord_run ? RD_FORM_ORDERED_TAIL : 0u) | (b->ft_run && b->ord_run ? RD_FORM_ONE_LAUNCH_TAIL : 0u) | (b->self_run ? RD_FORM_SELF_FIX : 0u) |
              (b->fused_run && !b->second_pass ? RD_FORM_FUSED_SEARCH : 0u) | (b->second_pass ? RD_FORM_SECOND_PASS : 0u);
     return RD_OK;
 }

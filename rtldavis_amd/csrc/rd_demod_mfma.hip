@@ -456,10 +456,23 @@ __device__ __forceinline__ int rd_lane_now() {
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// bucket_cnt != null (RD_DEMOD_FIX_BUCKETS, the one-launch tail): entry e of stream s goes to the bucket of the workgroup
+// of k_tail that owns s - fix_list[(s >> RD_FT_GSH) * fix_cap + slot], slot drawn from bucket_cnt[s >> RD_FT_GSH] - so
+// that each of those workgroups finds the words of its own streams without reading the whole list.  A wave flushes
+// ~11 entries once, at its end: 46 k returning atomics per launch spread over a thousand counters.
 __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count, uint32_t *fix_list, uint32_t fix_cap,
-                                            uint32_t *counters) {
+                                            uint32_t *counters, uint32_t bits_stride, uint32_t *bucket_cnt) {
     const int lane = rd_lane_now();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (bucket_cnt) {
+        for (uint32_t i = lane; i < count; i += 64) {
+            const uint32_t e = pend[i];
+            const uint32_t grp = ((e >> 4) / bits_stride) >> RD_FT_GSH;
+            const uint32_t slot = atomicAdd(&bucket_cnt[grp], 1u);  // (past fix_cap: k_tail sees the count and raises the overflow flag)
+            if (slot < fix_cap) fix_list[(size_t)grp * fix_cap + slot] = e;
+        }
+        return;
+    }
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&counters[RD_CNT_FIX], count);
     base = __builtin_amdgcn_readfirstlane(base);
@@ -737,6 +750,7 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
 #define RD_OPT_FSEARCH 64 // fused-search variant (rd_mf_search_tile), launched for RD_DEMOD_FUSED_SEARCH
 #define RD_OPT_FPROBE 16  // diagnostic library: what an in-tile preamble test would cost (rd_mf_search_probe)
 #define RD_STAMP_WORDS 12
+#define RD_STF_BUCKETS 8192u  // stflags: fix-up entries into per-group buckets (RD_DEMOD_FIX_BUCKETS)
 template <int DBG, int NBUF, int OPT>
 __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
                                                          uint32_t chunk, uint32_t *fix_list, uint32_t fix_cap,
@@ -759,6 +773,9 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     uint8_t *xb = s_xb[wave];
     uint32_t *mypend = s_pend[wave];
     uint32_t npend = 0;
+    // RD_STF_BUCKETS: the fix-up entries go to per-group buckets whose counters the last pointer argument names
+    constexpr bool CAN_BUCKET = DBG == 0 && !(OPT & (RD_OPT_FSEARCH | RD_OPT_STAMP | RD_OPT_SELF));
+    uint32_t *bucket_cnt = (CAN_BUCKET && (stflags & RD_STF_BUCKETS)) ? (uint32_t *)dbg_g : nullptr;
     uint32_t fs_nmatch = 0;  // fused search: entries in this wave's own match list (wave-uniform)
 
     const int n = lane & 31, h = lane >> 5;
@@ -1100,7 +1117,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         if (fm) {
             const uint32_t nf = (uint32_t)__popcll(fm);
             if (npend + nf > pend_limit) {  // (with self-fix: the rare overflow goes to the global list, k_fixup then runs)
-                rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
+                rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, (uint32_t)lay.bits_stride, bucket_cnt);
                 npend = 0;
             }
             if (gmask)
@@ -1118,7 +1135,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         if constexpr ((OPT & RD_OPT_SELF) != 0)
             rd_mf_selffix(pend_addr, npend, lay, counters + RD_CNT_QUEUE0 + (wave_id % RD_NQUEUE) * RD_QUEUE_STRIDE + RD_SELF_WORD);
         else
-            rd_mf_flush(mypend, npend, fix_list, fix_cap, counters);
+            rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, (uint32_t)lay.bits_stride, bucket_cnt);
     }
     if constexpr ((OPT & RD_OPT_FSEARCH) != 0) {
         if (rd_lane_now() == 0) {
@@ -1213,6 +1230,7 @@ struct rd_mf_launch_args {
     uint32_t stf_extra = 0;  // the self-fix variant's pending limit, or-ed into the kernel's stflags
     bool self_fix = false;
     const rd_mf_extra *extra = nullptr;  // fused-search variant
+    uint32_t *bucket_cnt = nullptr;      // RD_DEMOD_FIX_BUCKETS
     uint32_t *chunk_out = nullptr;
     float *dbg_g;
 };
@@ -1245,6 +1263,7 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
     if (wgs > max_wgs) wgs = max_wgs;
     float *dbg = a.dbg_g;
     if (OPT & RD_OPT_FSEARCH) dbg = (float *)a.extra;  // (the fused-search variant reads its extra arguments there)
+    else if (a.bucket_cnt && D == 0 && !(OPT & (RD_OPT_STAMP | RD_OPT_SELF))) dbg = (float *)a.bucket_cnt;
     if (a.chunk_out) { a.chunk_out[0] = chunk; a.chunk_out[1] = (uint32_t)wgs * RD_MF_WAVES; }
 #ifdef RD_DIAG
     if (OPT & RD_OPT_STAMP) {
@@ -1268,12 +1287,14 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
 
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                           hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t pend_limit,
-                          const rd_mf_extra *extra, uint32_t *chunk_out) {
+                          const rd_mf_extra *extra, uint32_t *chunk_out, uint32_t *bucket_cnt) {
     rd_mf_launch_args a;
     a.extra = (flags & RD_DEMOD_FUSED_SEARCH) ? extra : nullptr;
+    a.bucket_cnt = (flags & RD_DEMOD_FIX_BUCKETS) && !dbg_g ? bucket_cnt : nullptr;
     a.chunk_out = chunk_out;
     a.self_fix = (flags & RD_DEMOD_SELF_FIX) != 0;
     a.stf_extra = a.self_fix ? ((pend_limit & 0xFFu) << 16) : 0u;
+    if (a.bucket_cnt) a.stf_extra |= RD_STF_BUCKETS;
     a.lay = lay;
     a.tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     a.total64 = (uint64_t)lay.n_streams * a.tps;

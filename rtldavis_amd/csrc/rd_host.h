@@ -38,7 +38,7 @@ void rd_order_and_dedupe(const rd_packet *recs, size_t n, int S, rd_order_scratc
 // capacity is 4x the noise expectation plus 24 for bursts, rounded up to a multiple of 32 (one half-wave strip of
 // k_classify_ord), at least 32 and at most RD_BUCKET_MAX.
 #define RD_BUCKET_MIN 32
-#define RD_BUCKET_MAX 1024
+#define RD_BUCKET_MAX 512
 uint32_t rd_ord_bucket_cap(long n_samples);
 
 // py:32-36 / py:145-149: RD_OK when `count` elements are what one call takes (complex: B samples of one stream;

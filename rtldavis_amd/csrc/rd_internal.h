@@ -19,6 +19,18 @@ enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CN
 // rd_launch_demod flags
 #define RD_DEMOD_SELF_FIX 1u   /* a wave re-evaluates the groups it flagged itself when it has run out of tiles: no k_fixup launch */
 #define RD_DEMOD_FUSED_SEARCH 2u   /* the preamble test runs inside the demod kernel (Davis shape, per-stream buckets) */
+#define RD_DEMOD_FIX_BUCKETS 4u    /* the fix-up entries go to per-group buckets (the one-launch tail, k_tail): fix_list =
+                                      [groups][fix_cap] entries, bucket_cnt = [groups] counters, group = stream >> RD_FT_GSH */
+// The one-launch tail (rd_kernels.hip: k_tail): a workgroup owns RD_FT_STREAMS consecutive streams
+#define RD_FT_GSH 2
+#define RD_FT_STREAMS (1 << RD_FT_GSH)
+struct rd_ft_bufs {
+    uint32_t *fixb = nullptr;    // [groups][fix_bcap] fix-up entries, filled by the demod kernel's waves
+    uint32_t *fixcnt = nullptr;  // [groups] entries written (lives behind the counter set of the run: cleared with it)
+    uint32_t fix_bcap = 0;
+    uint32_t bcap = 0;           // matches a stream's list in LDS holds (a multiple of 32, rd_host.h: rd_ord_bucket_cap)
+    uint32_t *gstate = nullptr;  // [3][groups]: (seq << 20 | records), matches, fix-up entries per group
+};
 // What the fused-search variant of the demod kernel needs beyond its arguments (device memory, one per counter set;
 // the kernel receives its address in place of the test hook's output pointer)
 #define RD_WAVE_MATCHES 256  /* matches a demod wave keeps in its own list (16 on average at the bench workload, 70 at most) */
@@ -72,13 +84,14 @@ int rd_ensure_device_public(void);
 // (the boundary pass of the reduced search needs it)
 uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t flags = 0, uint32_t pend_limit = 0,
-                     const rd_mf_extra *extra = nullptr, uint32_t *chunk_out = nullptr);
+                     const rd_mf_extra *extra = nullptr, uint32_t *chunk_out = nullptr, uint32_t *bucket_cnt = nullptr);
 // The same stage with the FIR on the matrix pipe (rd_demod_mfma.hip); rd_launch_demod dispatches to it
 // unless RD_K1_IMPL=valu.  dbg_g (test hook): when given, the kernel also dumps g[tile][2048][2].
 void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr,
                           uint32_t flags = 0, uint32_t pend_limit = 0, const rd_mf_extra *extra = nullptr,
-                          uint32_t *chunk_out = nullptr);   // chunk_out[0] = tiles per chunk, [1] = waves launched
+                          uint32_t *chunk_out = nullptr,    // chunk_out[0] = tiles per chunk, [1] = waves launched
+                          uint32_t *bucket_cnt = nullptr);  // RD_DEMOD_FIX_BUCKETS: the groups' entry counters
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
@@ -122,6 +135,12 @@ int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bi
                            const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
                            uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop = nullptr,
                            uint32_t *zero_next = nullptr, uint32_t zero_words = 0, const rd_rem_args *rem = nullptr);
+// The whole tail in one launch (k_tail): exact bits for the listed groups, search, slice with order and dedupe, RSSI /
+// SNR, final records.  seq: 1..4095, different from the previous launch on fb.gstate.  skip_fix: the bits are final.
+// Returns 1 when launched, 0 when the shape is not the one the kernel is built for.
+int rd_launch_tail_fused(const rd_layout &lay, const rd_devcfg &cfg, int n_calls, long p_lo, long p_hi, const rd_ft_bufs &fb,
+                         uint32_t bucket_limit, uint32_t seq, int skip_fix, rd_packet *recs, uint32_t rec_cap, uint32_t *counters,
+                         hipStream_t st, hipEvent_t ev_stop = nullptr, uint32_t *zero_next = nullptr, uint32_t zero_words = 0);
 // Slice + RSSI/SNR, one wave per match.  batch_mode = 1: position = absolute sample, calls derived
 // from it (n_calls blocks from reset).  batch_mode = 0: position = window index q of call `call`,
 // lay.iq points at the newest block's first sample.

@@ -230,13 +230,15 @@ static const rd_k_params &rd_k_get_params() {
 
 uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                          hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t flags, uint32_t pend_limit, const rd_mf_extra *extra,
-                         uint32_t *chunk_out) {
+                         uint32_t *chunk_out, uint32_t *bucket_cnt) {
     const rd_k_params &P = rd_k_get_params();
     if (P.impl_mfma) {
         if (!extra) flags &= ~RD_DEMOD_FUSED_SEARCH;
         if (flags & RD_DEMOD_FUSED_SEARCH) flags &= ~RD_DEMOD_SELF_FIX;  // (the reduced search reads the global fix-up list)
-        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, pend_limit, extra, chunk_out);
-        return flags & (RD_DEMOD_SELF_FIX | RD_DEMOD_FUSED_SEARCH);
+        if (!bucket_cnt || (flags & (RD_DEMOD_SELF_FIX | RD_DEMOD_FUSED_SEARCH))) flags &= ~RD_DEMOD_FIX_BUCKETS;
+        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, pend_limit, extra, chunk_out,
+                             bucket_cnt);
+        return flags & (RD_DEMOD_SELF_FIX | RD_DEMOD_FUSED_SEARCH | RD_DEMOD_FIX_BUCKETS);
     }
     const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
@@ -1606,6 +1608,586 @@ int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bi
     else
         hipLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_otask *)ob.tasks, ob.wgtot, (int)cg,
                            cfg.nbytes, recs, rec_cap, counters);
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tail (round 4): the WHOLE tail of a batch run in ONE launch (Davis shape).  Until round 3 a run's tail was four
+// launches - k_fixup, k_search, k_classify_ord, k_rssi_ord: 102 us of kernels that are each a launch, a ramp and a
+// chain of dependent latencies, plus the gaps between dependent kernels of one stream.  Streams are independent
+// (dsp.py:131-135 holds all state per instance), so a workgroup that OWNS RD_FT_STREAMS consecutive streams can take
+// them through every stage without waiting for anybody:
+//   0. exact bits for the 8-sample groups the demod kernel listed for its streams (k_fixup's arithmetic; the demod
+//      kernel's waves put their entries into per-group buckets, rd_demod_mfma.hip: rd_mf_flush_buckets);
+//   1. Demodulator._search (py:171-188) over its streams' bits - k_search's funnel-shift test - the matches into
+//      per-stream lists in LDS;
+//   2. Demodulator._slice (py:190-205): calls (q <= B, py:194), packet bytes (py:197-200), the exact per-call dedupe
+//      (py:203-205) and the reference's order (phase-major inside a call, py:175-186), by rank among the stream's
+//      survivors; all in LDS (one lane per match, strips of 32 for long streams);
+//   3. RSSI / SNR (py:207-236) on the matrix pipe as k_rssi_u8 does, and the finished records at their FINAL position:
+//      the number of records of the groups in front comes from a word per group, published (agent scope) as soon as a
+//      group knows its total and read - spinning if need be - by the one wave per workgroup that needs it, while the
+//      other waves already evaluate windows.  A group only ever waits for groups with LOWER numbers, workgroups are
+//      dispatched in ascending order: the lowest unfinished group never waits, so the chain always advances (and a
+//      spin limit turns a bug into an error flag instead of a hang).
+// A stream with more matches than its list holds, more records than the output array, or a group whose fix-up bucket
+// overflowed raises RD_CNT_OVF bits (1, 2, 8; 16 = the spin limit): the host falls back to the separate kernels.
+// ------------------------------------------------------------------------------------------
+#define RD_FT_WG 256
+struct rd_ft_args {
+    rd_layout lay;
+    rd_devcfg cfg;
+    int n_calls;
+    int p_hi;                  // last position to report; the first is 0 (PRE_ starts with a one: zero bits in front of a stream match nothing)
+    int skip_fix;              // 1: the bits are final already (second pass after an exact re-evaluation of everything)
+    const uint32_t *fixb;      // [groups][fix_bcap] entries (word index << 4 | group mask)
+    const uint32_t *fixcnt;    // [groups] entries written (more than fix_bcap: the bucket overflowed)
+    uint32_t fix_bcap;
+    uint32_t bcap;             // matches a stream's list holds (a multiple of 32)
+    uint32_t bucket_limit;     // <= bcap (test hook: a smaller limit makes the overflow path run on ordinary inputs)
+    uint32_t *gstate;          // [3][groups]: (seq << 20 | records), matches, fix-up entries of each group
+    uint32_t seq;              // 1 .. 4095, different from the previous launch's on this buffer
+    rd_packet *recs;
+    uint32_t rec_cap;
+    uint32_t *counters;
+    uint32_t *zero_next;       // the handle's next counter set (cleared by workgroup 0) or null
+    uint32_t zero_words;
+    uint64_t *stamps;          // diagnostic library: [groups][8] s_memrealtime stamps of the phases (else null)
+    int abl;                   // diagnostic library, WRONG results: 1 search without the test, 2 without the loads, 3 without either
+};
+#ifdef RD_DIAG
+#define RD_FT_STAMP(k) do { if (a.stamps && (tid & 63) == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                                                               a.stamps[(size_t)grp * 8 + (k)] = t_; } } while (0)
+#else
+#define RD_FT_STAMP(k) do { } while (0)
+#endif
+
+// The preamble test of one output word with three-input logic (v_bitop3_b32: any boolean function of three operands in
+// one instruction): tap t contributes its shifted word or the complement, by the preamble's symbol t, and every
+// instruction folds two more taps into the running AND - 8 logic instructions per word for 16 taps, where and / or3 /
+// andn chains took 15 (the compiler's best), next to the 15 funnel shifts that produce the taps.
+template <int S_, int T>
+__device__ __forceinline__ uint32_t rd_tap(const uint32_t *r, int o) {
+    constexpr int wj = (T * S_) >> 5, sh = (T * S_) & 31;
+    return sh ? __builtin_amdgcn_alignbit(r[o + wj + 1], r[o + wj], sh) : r[o + wj];
+}
+// truth table of A' & B' & C' (X' = X when the symbol is one, else its complement); operands a, b, c = 0xF0, 0xCC, 0xAA
+constexpr int rd_tt3(bool pa, bool pb, bool pc) { return (pa ? 0xF0 : 0x0F) & (pb ? 0xCC : 0x33) & (pc ? 0xAA : 0x55); }
+template <int S_, int P_, uint64_t PRE_, int T>
+__device__ __forceinline__ uint32_t rd_match_from(uint32_t m, const uint32_t *r, int o) {
+    if constexpr (T >= P_) {
+        return m;
+    } else if constexpr (T + 1 == P_) {
+        const uint32_t v = rd_tap<S_, T>(r, o);
+        return __builtin_amdgcn_bitop3_b32(m, v, v, rd_tt3(true, (PRE_ >> T) & 1, (PRE_ >> T) & 1));
+    } else {
+        const uint32_t n = __builtin_amdgcn_bitop3_b32(m, rd_tap<S_, T>(r, o), rd_tap<S_, T + 1>(r, o),
+                                                       rd_tt3(true, (PRE_ >> T) & 1, (PRE_ >> (T + 1)) & 1));
+        return rd_match_from<S_, P_, PRE_, T + 2>(n, r, o);
+    }
+}
+template <int S_, int P_, uint64_t PRE_>
+__device__ __forceinline__ uint32_t rd_match_word(const uint32_t *r, int o) {
+    static_assert(P_ >= 3, "three taps in the first instruction");
+    const uint32_t m = __builtin_amdgcn_bitop3_b32(rd_tap<S_, 0>(r, o), rd_tap<S_, 1>(r, o), rd_tap<S_, 2>(r, o),
+                                                   rd_tt3(PRE_ & 1, (PRE_ >> 1) & 1, (PRE_ >> 2) & 1));
+    return rd_match_from<S_, P_, PRE_, 3>(m, r, o);
+}
+
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store in flight
+// (s_waitcnt vmcnt(0)) - here the stores that publish a group's totals, whose acknowledgement nobody in the
+// workgroup needs
+__device__ __forceinline__ void rd_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int S_, int P_, uint64_t PRE_, int K_>
+__global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
+    constexpr int G = RD_FT_STREAMS;
+    static_assert(PRE_ & 1, "positions below 0 are skipped because the preamble starts with a one");
+    static_assert(RD_FT_WG == 64 * G, "one wave per stream in the classify strips");
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    // s_t: per match {flags, call b0, key 0, key 1, bytes[3], result}; s_pos: the matches' positions; s_ord: the
+    // group's surviving tasks in final order (stream << 16 | match << 1 | which); s_res: their RSSI / SNR
+    uint32_t *s_t = s_dyn;
+    int32_t *s_pos = (int32_t *)(s_dyn + (size_t)G * a.bcap * 8);
+    uint32_t *s_ord = s_dyn + (size_t)G * a.bcap * 9;
+    __shared__ uint32_t s_cnt[G], s_kept[G];
+    __shared__ uint32_t s_ready;   // 0: not yet; else 1 + the number of records of the groups in front
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x, n_groups = gridDim.x;
+    const int stream0 = grp * G;
+    const int n_here = a.lay.n_streams - stream0 < G ? a.lay.n_streams - stream0 : G;
+    const int nwords = (int)((a.lay.n_samples + 31) / 32);
+    if (grp == 0 && a.zero_next)
+        for (uint32_t i = tid; i < a.zero_words; i += RD_FT_WG) a.zero_next[i] = 0;
+    if (tid < G) { s_cnt[tid] = 0; s_kept[tid] = 0; }
+    if (tid == 0) s_ready = 0;
+    if (wave == 0) RD_FT_STAMP(0);
+
+    // ---- 0. exact bits for the listed groups of this workgroup's streams (k_fixup's listed branch) ----
+    uint32_t n_fix_raw = 0;
+    if (!a.skip_fix) {
+        // One lane per (entry, listed 8-sample group), packed densely: the ~50 items of a group of streams fit ONE wave.
+        // (A lane per entry that took its groups one after the other - a stream's first run lists all four - held the
+        // workgroup at the barrier for four dependent rounds of loads and float64 arithmetic, 12 us; a lane per
+        // (entry, group) slot kept all four waves busy with the arithmetic for a handful of active lanes each.)
+        // An entry is asked for together with the count - a slot past the count holds an old run's entry or nothing, and
+        // is not used: one memory round trip instead of two.
+        const uint32_t *bk = a.fixb + (size_t)grp * a.fix_bcap;
+        const uint32_t e_first = (uint32_t)tid < a.fix_bcap ? bk[tid] : 0u;
+        n_fix_raw = a.fixcnt[grp];
+        const uint32_t n_fix = n_fix_raw < a.fix_bcap ? n_fix_raw : a.fix_bcap;
+        uint32_t *s_items = s_t;  // (the match table's space: 4 x 256 items at the least, not in use yet)
+        __shared__ uint32_t s_nitems;
+        static_assert(RD_GROUPS == 4, "an entry lists up to four groups");
+        for (uint32_t i0 = 0; i0 < n_fix; i0 += RD_FT_WG) {
+            if (tid == 0) s_nitems = 0;
+            __syncthreads();
+            const uint32_t i = i0 + (uint32_t)tid;
+            const uint32_t e = i < n_fix ? (i0 == 0 ? e_first : bk[i]) : 0u;
+            const uint32_t k = (uint32_t)__popc(e & 0xFu);
+            if (k) {
+                uint32_t at = atomicAdd(&s_nitems, k);
+                for (int g = 0; g < RD_GROUPS; g++)
+                    if ((e >> g) & 1) s_items[at++] = ((uint32_t)tid << 2) | (uint32_t)g;
+                s_items[4 * RD_FT_WG + tid] = e;   // (the entries themselves: 256 words behind the 1024 item slots)
+            }
+            __syncthreads();
+            const uint32_t n_items = s_nitems;
+            for (uint32_t it = (uint32_t)tid; it < n_items; it += RD_FT_WG) {
+                const uint32_t item = s_items[it];
+                const uint32_t ee = s_items[4 * RD_FT_WG + (item >> 2)];
+                const int g = (int)(item & 3u);
+                const uint32_t widx = ee >> 4;
+                const uint32_t s = widx / (uint32_t)a.lay.bits_stride;
+                const uint32_t run = widx - s * (uint32_t)a.lay.bits_stride;
+                const uint8_t *base = a.lay.iq + (size_t)s * a.lay.stream_stride;
+                const long t0 = (long)run * RD_RUN + g * RD_GROUP;
+                const long left = (long)a.lay.n_samples - t0;
+                if (left <= 0) continue;
+                const int count = left < RD_GROUP ? (int)left : RD_GROUP;
+                const uint8_t *p = base + 2 * (t0 - 10);
+                uint32_t dw[10];
+                const long x = a.lay.valid_from - (t0 - 10), z = (long)a.lay.n_samples + 8 - (t0 - 10);
+                const int d_lo = x <= 0 ? 0 : x >= 20 ? 10 : (int)(x / 2);
+                const int d_hi = z <= 0 ? 0 : z >= 20 ? 10 : (int)((z + 1) / 2);
+#pragma unroll
+                for (int d = 0; d < 10; d++) dw[d] = (d >= d_lo && d < d_hi) ? *(const uint32_t *)(p + 4 * d) : 0u;
+                ((uint8_t *)a.lay.bits)[(size_t)widx * 4 + g] = (uint8_t)rd_exact_group_dw(dw, t0, count, a.lay.valid_from);
+            }
+            if (i0 + RD_FT_WG < n_fix) __syncthreads();   // (the item list is rewritten by the next batch of entries)
+        }
+    }
+    // (the byte stores above are read below by other waves of this workgroup only: the barrier's workgroup-scope
+    // release / acquire covers them - all waves of a workgroup share the CU's vector L1)
+    __syncthreads();
+    if (wave == 0) RD_FT_STAMP(1);
+
+    // ---- 1. preamble search over this workgroup's streams: a wave = 64 lanes x 128 positions of one stream ----
+    // Three register buffers in rotation: the words of the two units after the one being tested are in flight (with one
+    // unit's loads waited for at the top of every trip this phase took 41 us of memory latency for 25 us of vector issue).
+    {
+        constexpr int NW = ((RD_SEARCH_OUT + ((P_ - 1) * S_ + 31) / 32 + 1 + 3) / 4) * 4;
+        const int gps = a.p_hi / (32 * RD_SEARCH_OUT) + 1;       // lane-groups per stream
+        const int wgps = (gps + 63) / 64;                         // wave-groups per stream
+        const int units = n_here * wgps;
+        // (unit u = wave-group u % wgps of stream u / wgps; the split is carried along in scalars - one division per
+        // unit was a fifth of this loop's bookkeeping)
+        auto fetch = [&](int g, int rem, uint32_t (&r)[NW]) {
+            const int gi = rem * 64 + lane;
+            const uint32_t *w = a.lay.bits + (size_t)(stream0 + g) * a.lay.bits_stride;
+            // Every lane loads, whatever its position: the lanes past the stream's last lane-group (the last wave-group
+            // of a stream only) read the stream's last NW words instead and report nothing.  No branch, no exec mask: the
+            // compiler's wait-count bookkeeping gave up on the guarded form of this ("wait for everything" in front of
+            // every prefetch), and the loads then ran between the tests instead of under them.  (The host checks that a
+            // reported position's window always lies inside the stream: p_hi / 32 + NW <= nwords.)
+            int w0 = RD_SEARCH_OUT * gi;
+            w0 = w0 + NW <= nwords ? w0 : nwords - NW;
+#pragma unroll
+            for (int j = 0; j < NW / 4; j++) {
+                const uint4 v4 = *(const uint4 *)(w + w0 + 4 * j);
+                r[4 * j] = v4.x; r[4 * j + 1] = v4.y; r[4 * j + 2] = v4.z; r[4 * j + 3] = v4.w;
+            }
+        };
+        auto test = [&](int g, int rem, const uint32_t (&r)[NW]) {
+            const int gi = rem * 64 + lane;
+            uint32_t m[RD_SEARCH_OUT] = {};
+            const int p0 = 32 * RD_SEARCH_OUT * gi;
+            if (gi < gps) {
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) m[o] = rd_match_word<S_, P_, PRE_>(r, o);
+                if (p0 + 32 * RD_SEARCH_OUT - 1 > a.p_hi) {  // only a stream's last words
+#pragma unroll
+                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                        const int q0 = p0 + 32 * o;
+                        if (q0 + 31 > a.p_hi) m[o] &= (a.p_hi < q0) ? 0u : (0xFFFFFFFFu >> (31 - (a.p_hi - q0)));
+                    }
+                }
+            }
+            uint32_t anym = 0;
+#pragma unroll
+            for (int o = 0; o < RD_SEARCH_OUT; o++) anym |= m[o];
+            if (__ballot(anym != 0)) {  // wave-uniform; 3 wave-groups in 10 on noise
+                uint32_t mine = 0;
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) mine += (uint32_t)__popc(m[o]);
+                uint32_t incl = mine;
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
+                    if (lane >= sh) incl += up;
+                }
+                const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+                uint32_t slot0 = 0;
+                if (lane == 0) slot0 = atomicAdd(&s_cnt[g], tot);
+                uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0) + incl - mine;
+#pragma unroll
+                for (int o = 0; o < RD_SEARCH_OUT; o++) {
+                    uint32_t mm = m[o];
+                    while (mm) {  // (lane-divergent, a few iterations at most)
+                        const int bpos = __builtin_ctz(mm);
+                        mm &= mm - 1;
+                        if (slot < a.bcap) s_pos[(size_t)g * a.bcap + slot] = p0 + 32 * o + bpos;
+                        slot++;
+                    }
+                }
+            }
+        };
+        uint32_t ra[NW], rb[NW], rc[NW];
+        // a wave's units: wave, wave + G, ...; (g, rem) of the unit to fetch next and of the unit to test next
+        const int dq = G / wgps, dr = G % wgps;
+        int fg = wave / wgps, fr = wave % wgps, fu = wave;
+        int tg = fg, tr = fr;
+        auto step = [&](int &gg, int &rr) { gg += dq; rr += dr; if (rr >= wgps) { rr -= wgps; gg++; } };
+#ifdef RD_DIAG
+        auto fetch_next = [&](uint32_t (&r)[NW]) { if (fu < units && !(a.abl & 2)) fetch(fg, fr, r); fu += G; step(fg, fr); };
+        auto test_next = [&](const uint32_t (&r)[NW]) { if (!(a.abl & 1)) test(tg, tr, r); else if (r[0] == 0x12345678u) s_cnt[0] = 1; step(tg, tr); };
+#else
+        auto fetch_next = [&](uint32_t (&r)[NW]) { if (fu < units) fetch(fg, fr, r); fu += G; step(fg, fr); };
+        auto test_next = [&](const uint32_t (&r)[NW]) { test(tg, tr, r); step(tg, tr); };
+#endif
+        fetch_next(ra);
+        fetch_next(rb);
+        for (int u = wave; u < units; u += 3 * G) {
+            fetch_next(rc);
+            test_next(ra);
+            if (u + G >= units) break;
+            fetch_next(ra);
+            test_next(rb);
+            if (u + 2 * G >= units) break;
+            fetch_next(rb);
+            test_next(rc);
+        }
+    }
+    if (wave == 0) RD_FT_STAMP(6);   // (wave 0's own end of the search: the barrier's wait is 2 - 6)
+    rd_barrier_lds();
+    if (wave == 0) RD_FT_STAMP(2);
+
+    // ---- 2. slice: one wave per stream, lanes = matches (strips of 64) ----
+    constexpr int NBITS = (K_ - 1) * S_ + 1;
+    constexpr int NU = (NBITS + 31) / 32;
+    constexpr int NWS = NU + 1;
+    static_assert(K_ % 8 == 0 && (K_ + 7) / 8 <= 12 && NWS <= 36, "packet bytes fit a task entry");
+    const int g = wave;                       // the stream of this wave
+    const int stream = stream0 + g;
+    const uint32_t nmatch = g < n_here ? s_cnt[g] : 0u;
+    const bool ovf = nmatch > a.bucket_limit;
+    const uint32_t count = ovf ? 0u : nmatch;  // (overflow: the host runs the separate kernels on this input)
+    uint32_t *tg = s_t + (size_t)g * a.bcap * 8;
+    const int B = a.cfg.B, L = a.cfg.L;
+    for (uint32_t j = lane; j < count; j += 64) {
+        const int pos = s_pos[(size_t)g * a.bcap + j];
+        const uint32_t *w = a.lay.bits + (size_t)stream * a.lay.bits_stride;
+        const int wi0 = pos >> 5;
+        const uint32_t sh = (uint32_t)(pos & 31);
+        uint32_t W[NWS];
+#pragma unroll
+        for (int i = 0; i < NWS; i++) W[i] = (wi0 + i < nwords) ? w[wi0 + i] : 0u;
+        // calls that report this position (py:194, q <= B)
+        const uint32_t pl = (uint32_t)(pos + L), bq = pl / (uint32_t)B, br = pl - bq * (uint32_t)B;
+        const int b0 = (int)bq - 1;
+        const int q0 = pos - ((b0 + 1) * B - L);
+        const bool ok0 = b0 >= 0 && b0 < a.n_calls;
+        const int b1 = b0 - 1, q1 = q0 + B;
+        const bool ok1 = br == 0 && b1 >= 0 && b1 < a.n_calls;
+        // the packet's bytes: byte bi = symbols 8 bi .. 8 bi + 7, first symbol = MSB (py:197-200)
+        uint32_t uu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) uu[i] = __builtin_amdgcn_alignbit(W[i + 1], W[i], sh);
+        uint32_t dw[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < K_; k++) {
+            const int bit = k * S_, bi = k >> 3;
+            const uint32_t b = (uu[bit >> 5] >> (bit & 31)) & 1u;
+            dw[bi >> 2] |= b << (8 * (bi & 3) + 7 - (k & 7));
+        }
+        // keys: (phase, q), the order of py:171-188 inside a call; task 0 = (b0, q0), task 1 = (b0 - 1, q0 + B)
+        const uint32_t ph0 = (uint32_t)q0 % (uint32_t)S_, ph1 = (uint32_t)q1 % (uint32_t)S_;
+        uint4 *e = (uint4 *)(tg + 8 * j);
+        e[0] = uint4{(ok0 ? 1u : 0u) | (ok1 ? 2u : 0u), (uint32_t)b0, (ph0 << 24) | (uint32_t)q0, (ph1 << 24) | (uint32_t)q1};
+        e[1] = uint4{dw[0], dw[1], dw[2], 0u};
+    }
+    // (a wave reads what the same wave wrote: LDS operations of a wave complete in order, no barrier needed)
+    // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205)
+    for (uint32_t j = lane; j < ((count + 63) & ~63u); j += 64) {
+        const bool live = j < count;
+        const uint4 me = live ? *(const uint4 *)(tg + 8 * j) : uint4{0, 0, 0, 0};
+        const uint4 md = live ? *(const uint4 *)(tg + 8 * j + 4) : uint4{0, 0, 0, 0};
+        const int b0 = (int)me.y, b1 = b0 - 1;
+        const uint32_t k0 = me.z, k1 = me.w;
+        bool dup0 = false, dup1 = false;
+        for (uint32_t i = 0; i < count; i++) {  // broadcast reads
+            const uint4 x = *(const uint4 *)(tg + 8 * i), d = *(const uint4 *)(tg + 8 * i + 4);
+            const int ob0 = (int)x.y;
+            const bool lower = i < j;  // equal keys = the same position twice: the lower slot counts as the earlier one
+            if (d.x == md.x && d.y == md.y && d.z == md.z) {
+                if ((x.x & 1u) && ob0 == b0 && (x.z < k0 || (x.z == k0 && lower))) dup0 = true;
+                if ((x.x & 2u) && ob0 - 1 == b0 && (x.w < k0 || (x.w == k0 && lower))) dup0 = true;
+                if ((x.x & 1u) && ob0 == b1 && (x.z < k1 || (x.z == k1 && lower))) dup1 = true;
+                if ((x.x & 2u) && ob0 - 1 == b1 && (x.w < k1 || (x.w == k1 && lower))) dup1 = true;
+            }
+        }
+        if (live) tg[8 * j + 7] = (((me.x & 1u) && !dup0) ? 1u : 0u) | (((me.x & 2u) && !dup1) ? 2u : 0u);
+    }
+    // pass 2: rank among the surviving tasks of the stream
+    uint32_t kept_here = 0;
+    for (uint32_t j = lane; j < ((count + 63) & ~63u); j += 64) {
+        const bool live = j < count;
+        const uint4 me = live ? *(const uint4 *)(tg + 8 * j) : uint4{0, 0, 0, 0};
+        const uint32_t mk = live ? tg[8 * j + 7] : 0u;
+        const int b0 = (int)me.y, b1 = b0 - 1;
+        const uint32_t k0 = me.z, k1 = me.w;
+        uint32_t r0 = 0, r1 = 0;
+        for (uint32_t i = 0; i < count; i++) {
+            const uint4 x = *(const uint4 *)(tg + 8 * i);
+            const uint32_t xk = tg[8 * i + 7] & 3u;
+            const int ob0 = (int)x.y;
+            auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
+            if (xk & 1u) { r0 += before(ob0, x.z, b0, k0) ? 1u : 0u; r1 += before(ob0, x.z, b1, k1) ? 1u : 0u; }
+            if (xk & 2u) { r0 += before(ob0 - 1, x.w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, x.w, b1, k1) ? 1u : 0u; }
+        }
+        kept_here += (uint32_t)__popcll(__ballot((mk & 1u) != 0)) + (uint32_t)__popcll(__ballot((mk & 2u) != 0));
+        if (live) tg[8 * j + 7] = mk | (r0 << 2) | (r1 << 17);   // (ranks < 2 bcap <= 2^15)
+    }
+    if (lane == 0) s_kept[g] = kept_here;
+    if (ovf && lane == 0) atomicOr(&a.counters[RD_CNT_OVF], 1u);
+    rd_barrier_lds();
+    // the group's list: its streams' tasks one stream after the other, each stream's in rank order
+    uint32_t off = 0, total = 0, mtotal = 0;
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        off += i < g ? s_kept[i] : 0u;
+        total += s_kept[i];
+        mtotal += i < n_here ? s_cnt[i] : 0u;
+    }
+    for (uint32_t j = lane; j < count; j += 64) {
+        const uint32_t res = tg[8 * j + 7];
+        if (res & 1u) s_ord[off + ((res >> 2) & 0x7FFFu)] = ((uint32_t)g << 16) | (j << 1);
+        if (res & 2u) s_ord[off + (res >> 17)] = ((uint32_t)g << 16) | (j << 1) | 1u;
+    }
+    // Publish the group's totals: three self-validating words (this launch's sequence number in the top twelve bits),
+    // relaxed agent-scope stores - no release fence: at agent scope that is a write-back of the XCD's whole L2
+    // (buffer_wbl2), once per workgroup, and an acquire on the reading side an invalidate per poll; the first version
+    // of this kernel had both and took 165 us instead of 60.  Nothing else travels between workgroups.
+    const uint32_t tag = (a.seq & 0xFFFu) << 20;
+    if (tid == 0) {
+        __hip_atomic_store(&a.gstate[grp], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.gstate[n_groups + grp], tag | (mtotal < 0xFFFFFu ? mtotal : 0xFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.gstate[2 * n_groups + grp], tag | (n_fix_raw < 0xFFFFFu ? n_fix_raw : 0xFFFFFu), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (n_fix_raw > a.fix_bcap) atomicOr(&a.counters[RD_CNT_OVF], 8u);
+    }
+    rd_barrier_lds();
+    if (wave == 0) RD_FT_STAMP(3);
+
+    // ---- 3. RSSI / SNR and the records ----
+    if (wave == G - 1) {
+        // records of the groups in front: one word each, valid once it carries this launch's sequence number
+        uint32_t polls = 0;
+        bool gave_up = false;
+        auto tagged = [&](const uint32_t *p) -> uint32_t {  // the value behind this launch's tag (spins until it is there)
+            for (;;) {
+                const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v & 0xFFF00000u) == tag) return v & 0xFFFFFu;
+                if (++polls > (1u << 22)) { gave_up = true; return 0u; }  // (seconds: never, unless something is broken)
+                __builtin_amdgcn_s_sleep(8);
+            }
+        };
+        // (sixteen words per lane asked for before the first is looked at: one memory round trip per 1024 groups in
+        // front, where a loop of dependent polls took one per 64)
+        uint32_t sum = 0;
+        for (int j0 = 0; j0 < grp; j0 += 1024) {
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int j = j0 + lane + 64 * k;
+                v[k] = j < grp ? __hip_atomic_load(&a.gstate[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if ((v[k] & 0xFFF00000u) != tag) v[k] = tag | tagged(&a.gstate[j0 + lane + 64 * k]);  // not there yet: poll
+                sum += v[k] & 0xFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+        if (lane == 0) __hip_atomic_store(&s_ready, sum + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (grp == n_groups - 1) {  // the last group leaves the run's totals for the host
+            uint32_t mt = 0, ft = 0;
+            for (int i = lane; i < n_groups; i += 64) { mt += tagged(&a.gstate[n_groups + i]); ft += tagged(&a.gstate[2 * n_groups + i]); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mt += (uint32_t)__shfl_xor((int)mt, o, 64);
+                ft += (uint32_t)__shfl_xor((int)ft, o, 64);
+            }
+            if (lane == 0) {
+                a.counters[RD_CNT_TASKS] = sum + total;
+                a.counters[RD_CNT_MATCH] = mt;
+                a.counters[RD_CNT_FIX] = ft;
+                if (sum + total > a.rec_cap) atomicOr(&a.counters[RD_CNT_OVF], 2u);
+            }
+        }
+        if (__ballot(gave_up) && lane == 0) atomicOr(&a.counters[RD_CNT_OVF], 16u);
+        RD_FT_STAMP(4);
+    }
+    // every wave evaluates its share of the windows; the results wait in LDS for the group's first record number
+    float *s_res = (float *)(s_dyn + (size_t)G * a.bcap * 11);
+    if ((uint32_t)wave < total) {
+        rd_k_h8 Ahi[3], Alo[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
+            Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
+        }
+        struct task { int stream, call, q; };
+        auto task_at = [&](uint32_t r) {
+            const uint32_t o = s_ord[r];
+            const uint32_t *e = s_t + ((size_t)(o >> 16) * a.bcap + ((o >> 1) & 0x7FFFu)) * 8;
+            task t;
+            t.stream = stream0 + (int)(o >> 16);
+            t.call = (int)e[1] - (int)(o & 1u);
+            t.q = (int)(e[2] & 0xFFFFFFu) + ((o & 1u) ? B : 0);
+            return t;
+        };
+        auto view = [&](int s) {
+            rd_stream_view v;
+            v.base = a.lay.iq + (size_t)s * a.lay.stream_stride;
+            v.valid_from = a.lay.valid_from;
+            v.n = a.lay.n_samples;
+            return v;
+        };
+        auto job_of = [&](const task &t) {
+            return rd_rssi_prepare(view(__builtin_amdgcn_readfirstlane(t.stream)), __builtin_amdgcn_readfirstlane(t.call) * B, a.cfg,
+                                   __builtin_amdgcn_readfirstlane(t.q), lane);
+        };
+        task t_cur = task_at((uint32_t)wave);
+        rd_rssi_job j_cur = job_of(t_cur);
+        rd_rssi_data d_cur = {};
+        if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+        for (uint32_t r = (uint32_t)wave; r < total; r += G) {
+            const task t_now = t_cur;
+            const rd_rssi_job j_now = j_cur;
+            const rd_rssi_data d_now = d_cur;
+            if (r + G < total) {  // the next task's bytes are in flight under this one's arithmetic
+                t_cur = task_at(r + G);
+                j_cur = job_of(t_cur);
+                if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
+            }
+            double rssi = 0.0, snr = 0.0;
+            if (j_now.ok) {
+                float noise, sig;
+                rd_rssi_block(j_now, d_now, Ahi, Alo, lane, noise, sig);
+                rd_rssi_finish(noise, sig, j_now.ns, j_now.pe, j_now.q, lane, rssi, snr);
+            } else {  // a window that reaches outside the stream: the fp32 path with its per-sample checks
+                rd_rssi_u8(view(__builtin_amdgcn_readfirstlane(t_now.stream)), (long)__builtin_amdgcn_readfirstlane(t_now.call) * B, a.cfg,
+                           (long)__builtin_amdgcn_readfirstlane(t_now.q), lane, rssi, snr);
+            }
+            // (both figures are float values widened to double - 3.0103 * v_log_f32 or the constants of py:233,236)
+            if (lane == 0) { s_res[2 * r] = (float)rssi; s_res[2 * r + 1] = (float)snr; }
+        }
+    }
+    rd_barrier_lds();
+    // the records, one lane each, at the group's first record number + rank (known by now, as a rule)
+    if ((uint32_t)tid < total) {
+        uint32_t spins = 0, v = 0;
+        while (!(v = __hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) && ++spins < (1u << 24))
+            __builtin_amdgcn_s_sleep(2);
+        const uint32_t first = v - 1u;
+        for (uint32_t r = (uint32_t)tid; r < total; r += RD_FT_WG) {
+            const uint32_t o = s_ord[r];
+            const uint32_t *e = s_t + ((size_t)(o >> 16) * a.bcap + ((o >> 1) & 0x7FFFu)) * 8;
+            const uint4 x = *(const uint4 *)e, d = *(const uint4 *)(e + 4);
+            const uint32_t at = first + r;
+            if (at < a.rec_cap) {
+                const double rssi = (double)s_res[2 * r], snr = (double)s_res[2 * r + 1];
+                uint4 *out = (uint4 *)&a.recs[at];
+                out[0] = uint4{(uint32_t)(stream0 + (int)(o >> 16)), (uint32_t)((int)x.y - (int)(o & 1u)),
+                               (uint32_t)((int)(x.z & 0xFFFFFFu) + ((o & 1u) ? B : 0)), (uint32_t)a.cfg.nbytes};
+                out[1] = uint4{d.x, d.y, d.z, 0u};
+                out[2] = uint4{0u, 0u, 0u, 0u};
+                const uint2 rb = __builtin_bit_cast(uint2, rssi), sb = __builtin_bit_cast(uint2, snr);
+                out[3] = uint4{rb.x, rb.y, sb.x, sb.y};
+            }
+        }
+    }
+    if (wave == 0) RD_FT_STAMP(5);
+}
+
+#ifdef RD_DIAG
+static uint64_t *g_ft_stamps = nullptr;
+static uint32_t g_ft_groups = 0;
+// stamps of the last k_tail launch (diagnostic library): 8 uint64 per group (s_memrealtime, 100 MHz)
+extern "C" int rd_diag_read_tail_stamps(uint64_t *out, uint32_t cap_groups, uint32_t *n_groups) {
+    if (!g_ft_stamps || !n_groups) return RD_ERR_STATE;
+    if (hipDeviceSynchronize() != hipSuccess) return RD_ERR_DEVICE;
+    *n_groups = g_ft_groups;
+    const uint32_t n = g_ft_groups < cap_groups ? g_ft_groups : cap_groups;
+    if (n && hipMemcpy(out, g_ft_stamps, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) return RD_ERR_DEVICE;
+    return RD_OK;
+}
+#endif
+
+size_t rd_tail_fused_lds(uint32_t bcap) { return (size_t)RD_FT_STREAMS * bcap * (8 + 1 + 2 + 4) * sizeof(uint32_t); }
+
+// returns 1 when the fused tail was launched, 0 when the shape is not the one it is built for
+int rd_launch_tail_fused(const rd_layout &lay, const rd_devcfg &cfg, int n_calls, long p_lo, long p_hi, const rd_ft_bufs &fb,
+                         uint32_t bucket_limit, uint32_t seq, int skip_fix, rd_packet *recs, uint32_t rec_cap, uint32_t *counters,
+                         hipStream_t st, hipEvent_t ev_stop, uint32_t *zero_next, uint32_t zero_words) {
+    const long n_bits = lay.n_samples;
+    if (!(cfg.S == 14 && cfg.P == 16 && cfg.K == 80 && cfg.pre_mask == 0x91D3ull) || n_bits >= (1l << 30) || cfg.B >= (1 << 24) ||
+        lay.n_streams <= 0 || p_lo > 0 || p_hi < 0 || p_hi >= (1l << 30) || !fb.gstate || !fb.fixb || fb.bcap == 0 || fb.bcap % 32 ||
+        fb.bcap > RD_BUCKET_MAX || lay.bits_stride % 4 || ((size_t)lay.bits % 16) || lay.hist_mode ||
+        p_hi / 32 + 16 > (n_bits + 31) / 32)   // (a reported position's 12-word window inside the stream: k_tail's search loads)
+        return 0;
+    rd_ft_args a;
+    a.lay = lay; a.cfg = cfg; a.n_calls = n_calls; a.p_hi = (int)p_hi; a.skip_fix = skip_fix;
+    a.fixb = fb.fixb; a.fixcnt = fb.fixcnt; a.fix_bcap = fb.fix_bcap;
+    a.bcap = fb.bcap; a.bucket_limit = bucket_limit < fb.bcap ? bucket_limit : fb.bcap;
+    a.gstate = fb.gstate; a.seq = seq;
+    a.recs = recs; a.rec_cap = rec_cap; a.counters = counters; a.zero_next = zero_next; a.zero_words = zero_words;
+    a.stamps = nullptr;
+    a.abl = 0;
+    const uint32_t groups = (uint32_t)(lay.n_streams + RD_FT_STREAMS - 1) / RD_FT_STREAMS;
+#ifdef RD_DIAG
+    if (const char *e = getenv("RD_FT_ABL")) a.abl = atoi(e);
+    if (getenv("RD_FT_STAMPS")) {
+        if (groups > g_ft_groups) { if (g_ft_stamps) hipFree(g_ft_stamps); g_ft_stamps = nullptr; if (hipMalloc(&g_ft_stamps, (size_t)groups * 64) != hipSuccess) g_ft_stamps = nullptr; }
+        g_ft_groups = g_ft_stamps ? groups : 0;
+        a.stamps = g_ft_stamps;
+    }
+#endif
+    // at least 33 KiB per workgroup: FOUR workgroups per CU (one wave of each per SIMD) and never five - the register
+    // budget would admit a fifth, and the CUs that got one ran their search a third slower than the rest while every
+    // group behind them waited for their totals
+    const size_t lds = std::max<size_t>(rd_tail_fused_lds(fb.bcap), 33 * 1024);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        hipFuncSetAttribute((const void *)k_tail<14, 16, 0x91D3ull, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    if (ev_stop)
+        hipExtLaunchKernelGGL((k_tail<14, 16, 0x91D3ull, 80>), dim3(groups), dim3(RD_FT_WG), (unsigned)lds, st, nullptr, ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL((k_tail<14, 16, 0x91D3ull, 80>), dim3(groups), dim3(RD_FT_WG), (unsigned)lds, st, a);
     return 1;
 }
 

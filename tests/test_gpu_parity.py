@@ -987,7 +987,7 @@ def test_fused_search_equals_the_fixtures_and_the_c_oracle(dsp, batchmod, golden
         res = bd.demodulate(raw)
         for i, seed in enumerate(seeds):
             assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
-        assert bd.last_run_forms() == {"ordered_tail": True, "self_fix": False, "fused_search": True, "second_pass": False}
+        assert bd.last_run_forms() == {"ordered_tail": True, "self_fix": False, "fused_search": True, "second_pass": False, "one_launch_tail": False}
     bd.close()
     starts = [32768 - 448 - 300 + 12 * k for k in range(34)] + [8 * 8192 - 448 - 120 + 12 * k for k in range(14)]
     swept = np.stack([synth.synth_stream(100 + k, start=st) for k, st in enumerate(starts)])
@@ -1157,3 +1157,99 @@ def test_pipelined_handle_rerun_on_another_stream(dsp, batchmod, golden_streams)
     bd.close()           # destroyed with a run waiting on st2
     other.run(st2)
     check(other, [0, 1])
+
+
+# ---------------------------------------------------------------- round 4: the one-launch tail (k_tail)
+@pytest.mark.gpu
+def test_one_launch_tail_is_the_default_and_equals_the_other_forms(dsp, batchmod, golden_streams, monkeypatch):
+    """Everything behind the demod kernel - exact bits for the listed groups, Demodulator._search and ._slice
+    (dsp.py:171-246: order, dedupe, RSSI / SNR) - runs as ONE launch by default; RD_TAIL_IMPL=ordered / legacy select
+    round 3's four launches and the unordered kernels + host ordering.  All three: the fixtures' packets, the same
+    records field for field, the same bits.  13 streams: three whole groups of four and a partial one."""
+    seeds = list(range(13))
+    raw = synth.synth_streams(seeds)
+    out = {}
+    for impl in (None, "ordered", "legacy"):
+        if impl is None:
+            monkeypatch.delenv("RD_TAIL_IMPL", raising=False)
+        else:
+            monkeypatch.setenv("RD_TAIL_IMPL", impl)
+        bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+        bd.upload(raw)
+        for _ in range(3):      # both counter sets, the sequence numbers of the groups' totals
+            bd.run()
+            rec = bd.results().copy()
+        forms = bd.last_run_forms()
+        assert forms["one_launch_tail"] == (impl is None) and forms["ordered_tail"] == (impl != "legacy") and not forms["second_pass"]
+        res = bd.packets()
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+            assert sha(bd.bits(i)) == golden_streams[str(seed)]["bits_sha256"]
+        out[impl] = (rec, bd.counters())
+    for impl in ("ordered", "legacy"):
+        a, b = out[None][0], out[impl][0]
+        assert len(a) == len(b)
+        for f in ("stream", "call", "index", "nbytes", "data"):
+            assert np.array_equal(a[f], b[f]), (impl, f)
+        assert np.allclose(a["rssi"], b["rssi"], atol=1e-4, rtol=0) and np.allclose(a["snr"], b["snr"], atol=1e-4, rtol=0)
+        assert out[None][1] == out[impl][1], "fix-up and match counts differ between the forms"
+
+
+@pytest.mark.gpu
+def test_long_streams_size_their_match_lists(dsp, batchmod):
+    """the per-stream match lists are sized from the stream's length (rd_host.h:
+    rd_ord_bucket_cap): 330 blocks of noise with ten bursts (each stream = ten fixture-style streams back to back) hold
+    ~45 raw preamble matches per stream - more than the 32 of round 3's buckets - and still take the one-launch
+    tail in its first pass.  Packets and bits against the C oracle (dsp.py:171-246)."""
+    from oracle import c_oracle as CO
+    ns, parts = 6, 10
+    raw = np.stack([np.concatenate([synth.synth_stream(100 + 17 * s + k) for k in range(parts)]) for s in range(ns)])
+    nb = parts * synth.BLOCKS_PER_STREAM
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), ns, nb)
+    res = bd.demodulate(raw)
+    forms = bd.last_run_forms()
+    assert forms["one_launch_tail"] and forms["ordered_tail"] and not forms["second_pass"]
+    want, wbits = CO.demod_batch(raw, CO.make_cfg(), threads=4, want_bits=True)
+    assert max(len(w) for w in want) > 32
+    for i in range(ns):
+        assert np.array_equal(bd.bits(i), wbits[i]), i
+        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+        assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]], i
+        flat = [p for ps in res[i] for p in ps]
+        for p, q in zip(flat, want[i]):
+            assert abs(p.rssi - q.rssi) < 1e-3 and abs(p.snr - q.snr) < 1e-3
+
+
+@pytest.mark.gpu
+def test_one_launch_tail_overflows_fall_back(dsp, batchmod, golden_streams, monkeypatch):
+    """The one-launch tail's two overflows on ordinary inputs.  A stream with more matches than its list
+    (RD_TEST_BUCKET_CAP=2): the separate kernels finish the run on the bits k_tail has already made exact.  A group's
+    fix-up bucket (RD_TEST_FIX_BCAP=8): every run is re-evaluated exactly, then the separate kernels.
+    Both: second_pass reported, results = fixtures / C oracle."""
+    from oracle import c_oracle as CO
+    monkeypatch.setenv("RD_TEST_BUCKET_CAP", "2")
+    seeds = list(range(6))
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
+    res = bd.demodulate(synth.synth_streams(seeds))
+    f = bd.last_run_forms()
+    assert f["second_pass"] and not f["ordered_tail"]
+    for i, seed in enumerate(seeds):
+        assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+    monkeypatch.delenv("RD_TEST_BUCKET_CAP")
+    monkeypatch.setenv("RD_TEST_FIX_BCAP", "8")   # a group lists ~40 words (chunk starts, first runs): every bucket overflows
+    rng = np.random.default_rng(3)
+    nb = 8
+    raw = np.stack([rng.integers(126, 130, size=2 * 8192 * nb, dtype=np.uint8) for _ in range(5)] +
+                   [synth.synth_stream(9)[: 2 * 8192 * nb]])
+    bd = batchmod.BatchDemodulator(prod_cfg(dsp), raw.shape[0], nb)
+    want, wbits = CO.demod_batch(raw, CO.make_cfg(), threads=4, want_bits=True)
+    for _ in range(2):   # (the second run of the same input goes straight to the separate kernels)
+        bd.upload(raw)
+        bd.run()
+        res = bd.packets()
+        f = bd.last_run_forms()
+        assert f["second_pass"] and not f["one_launch_tail"]
+        for i in range(raw.shape[0]):
+            assert np.array_equal(bd.bits(i), wbits[i]), i
+            got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
+            assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
