@@ -71,11 +71,6 @@ def parse_args():
                     help="1: rd_batch_set_pipelined on every resident batch - a run's completion rides on the next run's "
                          "demod kernel instead of an event on its own last kernel (no idle gap between runs; use with "
                          "--resident 3 so that the host stays a whole step ahead)")
-    ap.add_argument("--self-fix", action="store_true",
-                    help="RD_FIXUP_IMPL=self: the demod kernel re-evaluates its flagged groups itself, no k_fixup launch "
-                         "(a shorter step, a longer demod kernel: profiles/r03_self_fix.txt)")
-    ap.add_argument("--fused-search", action="store_true",
-                    help="RD_SEARCH_IMPL=fused: the preamble test inside the demod kernel (profiles/r03_fused_search.txt)")
     ap.add_argument("--stage-times", action="store_true", help="time every kernel stage (adds events)")
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "
@@ -357,10 +352,6 @@ def main():
         np.stack([synth.synth_stream(s, n_samples=max(n_samples, 3 * 8192 + 2000))[: 2 * n_samples] for s in seeds])
     reps = (n_streams + nu - 1) // nu
     host = np.tile(uniq, (reps, 1))[:n_streams]
-    if args.self_fix:
-        os.environ["RD_FIXUP_IMPL"] = "self"   # read when a handle allocates its buffers
-    if args.fused_search:
-        os.environ["RD_SEARCH_IMPL"] = "fused"
     bds = [batch.BatchDemodulator(cfg, n_streams, n_blocks) for _ in range(max(2, args.resident))]
     bd = bds[0]
     t_h2d = time.perf_counter()
@@ -581,8 +572,7 @@ def main():
                            for k in (("demod_ms", "fixup_ms", "search_ms", "slice_ms", "total_ms") if args.stage_times
                                      else ("demod_ms", "total_ms"))},
             "completion": "pipelined" if args.pipelined else "per run",
-            "fixup": "self" if os.environ.get("RD_FIXUP_IMPL", "").startswith("s") else "k_fixup",
-            "search": "fused" if os.environ.get("RD_SEARCH_IMPL", "").startswith("f") else "k_search",
+            "tail": "separate kernels + host ordering" if os.environ.get("RD_TAIL_IMPL", "").startswith("l") else "k_tail (one launch)",
             "fixup_runs_frac": round(cnt["fixup_runs"] * 32 / (n_streams * n_samples), 5),
             "packets_per_step": len(recs), "verified_vs_reference_fixtures": verified,
             "h2d_s": round(t_h2d, 3),

@@ -140,6 +140,18 @@ int rd_demod_blocks(rd_demod *h, const uint8_t *iq, size_t nbytes, rd_packet *ou
  * The state mirrors below need a quiet handle (everything fetched).
  */
 int rd_demod_submit(rd_demod *h, const void *samples, size_t count, int is_complex);
+/*
+ * The same without ANY copy on the way in - SURVEY section 8f-4's "pinned-memory ring replacing the pickled-ndarray
+ * queue hop" (/root/reference/src/rtldavis/runners/rtlsdr.py:100-103 `data_queue.put(samples)` ->
+ * /root/reference/src/rtldavis/worker.py:37 `data_queue.get()`): rd_demod_register_input pins a buffer the PRODUCER owns
+ * (a multiprocessing.shared_memory ring an SDR process fills, rtldavis_amd/ring.py) and maps it into the device;
+ * rd_demod_submit_from launches on the block that lies at `offset` bytes into it (16-byte aligned; count as for
+ * rd_demod_submit) - the one-launch block reads it across the bus where it is.  The block must stay untouched until its
+ * rd_demod_fetch has returned.  One buffer per handle; registering again replaces it, host = NULL unregisters
+ * (rd_destroy does too); needs a quiet handle.
+ */
+int rd_demod_register_input(rd_demod *h, void *host, size_t nbytes);
+int rd_demod_submit_from(rd_demod *h, size_t offset, size_t count, int is_complex);
 int rd_demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n);
 int rd_demod_inflight(rd_demod *h);
 /*
@@ -205,8 +217,6 @@ int rd_batch_set_pipelined(rd_batch *b, int enabled);
 /* Which forms of the kernels the last run took (it is waited for first; no counterpart in the reference - for tests and
  * tools that must know that an opt-in form really ran and did not fall back): a mask of RD_FORM_*. */
 #define RD_FORM_ORDERED_TAIL 1u   /* records ordered and deduped on the device */
-#define RD_FORM_SELF_FIX 2u       /* RD_FIXUP_IMPL=self: no k_fixup launch */
-#define RD_FORM_FUSED_SEARCH 4u   /* RD_SEARCH_IMPL=fused: preamble test inside the demod kernel */
 #define RD_FORM_SECOND_PASS 8u    /* a list or bucket overflowed: search and slice ran a second time, in full */
 #define RD_FORM_ONE_LAUNCH_TAIL 16u /* everything behind the demod kernel ran as ONE launch (k_tail; implies ORDERED_TAIL) */
 int rd_batch_last_run_forms(rd_batch *b, uint32_t *forms);

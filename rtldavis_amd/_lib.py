@@ -59,6 +59,8 @@ SIGNATURES = {
     "rd_demod_blocks": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),
     "rd_copy_discriminated_stream": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "rd_demod_submit": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "rd_demod_register_input": (C.c_int, [_P, _P, C.c_size_t]),
+    "rd_demod_submit_from": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_int]),
     "rd_demod_fetch": (C.c_int, [_P, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),
     "rd_demod_refetch": (C.c_int, [_P, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),
     "rd_demod_inflight": (C.c_int, [_P]),

@@ -105,8 +105,7 @@ class BatchDemodulator:
         """Which forms the last run took (rd_batch_last_run_forms): for tests of the opt-in forms."""
         f = C.c_uint32()
         _lib.check(_lib.lib().rd_batch_last_run_forms(self._b, C.byref(f)))
-        return {"ordered_tail": bool(f.value & 1), "self_fix": bool(f.value & 2), "fused_search": bool(f.value & 4),
-                "second_pass": bool(f.value & 8), "one_launch_tail": bool(f.value & 16)}
+        return {"ordered_tail": bool(f.value & 1), "second_pass": bool(f.value & 8), "one_launch_tail": bool(f.value & 16)}
 
     def counters(self) -> dict:
         f, m = C.c_uint64(), C.c_uint64()

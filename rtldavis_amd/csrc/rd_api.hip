@@ -182,41 +182,26 @@ struct rd_batch {
     uint32_t spec_recs = 1024;       // records copied back speculatively with the counters
     uint64_t last_fix = 0, last_match = 0;
     rd_timing last_timing = {};
-    // The ordered tail (rd_launch_tail_ordered): records arrive in the reference's order with the per-call duplicates
-    // dropped, and rd_batch_results only copies them.  ord_ok: the buffers exist (Davis shape); ord_run: the run in
-    // flight used it; ord_off: an input overflowed its per-stream buckets - unordered kernels + host ordering until
-    // the next upload.
-    rd_ord_bufs ord;
-    bool ord_ok = false, ord_run = false, ord_off = false;
-    uint32_t bucket_limit = RD_BUCKET;
+    // dev_order: the run in flight left its records in the reference's order with the per-call duplicates dropped
+    // (k_tail), and rd_batch_results only copies them.  tail_off: an input overflowed k_tail's lists - the separate
+    // kernels + host ordering until the next upload.
+    bool dev_order = false, tail_off = false;
+    size_t cnt_stride = RD_CNT_TOTAL;  // words per counter set (k_tail's per-group fix-up counters live behind the counters)
     // The one-launch tail (round 4, rd_launch_tail_fused: k_tail): fix-up, search, slice with order and dedupe, RSSI and
     // the final records in ONE kernel, a workgroup per RD_FT_STREAMS streams; the demod kernel's waves put their fix-up
     // entries into per-group buckets (RD_DEMOD_FIX_BUCKETS) and no k_fixup is launched.  ft_ok: the buffers exist
     // (Davis shape, RD_TAIL_IMPL unset); ft_run: the run in flight used it; its overflows (a stream's match list, a
-    // group's fix-up bucket) send this input through the separate kernels (ord_off, as for the ordered tail) and the
-    // next upload gets lists twice as long.
+    // group's fix-up bucket) send this input through the separate kernels (tail_off) and the next upload gets lists
+    // twice as long.
     rd_ft_bufs ft;
     bool ft_ok = false, ft_run = false;
     uint32_t ft_seq = 0, ft_limit = 0;   // ft_limit: test hook RD_TEST_BUCKET_CAP (0: none)
     bool ft_sticky = false;              // an input overflowed the longest match lists: uploads no longer re-enable k_tail
     size_t ft_cnt_off = 0;               // the groups' fix-up counters inside a counter set (words)
-    size_t cnt_stride = RD_CNT_TOTAL;  // words per counter set (the per-stream match counters live behind the counters)
     // Pipelined completion (rd_batch_set_pipelined): the run's last kernel carries no event; the readback is hung on
     // the stop event of the NEXT demod kernel launched on the same stream (any handle's), see batch_adopt below.
-    // Self-fix: the demod kernel's waves re-evaluate the groups they flagged themselves (rd_demod_mfma.hip:
-    // rd_mf_selffix) and no k_fixup is launched; the search kernel clears the next counter set.  self_run: the run in
-    // flight was launched that way; self_redo: its (rare) overflow into the global list has been dealt with.
-    bool self_fix = false, self_run = false;
-    // Fused search (RD_SEARCH_IMPL=fused): the demod kernel does the preamble test (rd_mf_search_tile) and k_search_rem
-    // the windows around the fix-up list's words and the chunk starts; ordered tail only.  d_extra: the kernel's extra
-    // arguments, one per counter set.
-    bool fused = false, fused_run = false;
     bool second_pass = false;   // the run in flight needed a second search / slice pass (a list or bucket overflowed)
-    rd_mf_extra *d_extra = nullptr;
-    int2 *d_wmatch = nullptr;          // the demod waves' own match lists and their counts (fused search)
-    uint32_t *d_wcount = nullptr;
     uint32_t last_launch[2] = {0, 0};  // tiles per chunk and waves of the last demod launch
-    uint32_t self_pend_limit = 0;   // test hook RD_TEST_SELF_PEND: entries a wave keeps before the global list
     bool pipelined = false;
     bool deferred = false;          // the run in flight has no completion event yet (guarded by g_tail_mx)
     hipEvent_t kfirst = nullptr;    // stop event of this handle's demod launch when it adopts another run untimed
@@ -295,38 +280,22 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipMemset(b->d_iq + b->iq_bytes, 127, RD_INPUT_PAD));
     HIPCHK(hipMalloc(&b->d_bits, runs * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b->d_fix, (size_t)b->fix_cap * sizeof(uint32_t)));
-    // ordered tail: Davis shape only (the kernels are compiled for it); RD_TAIL_IMPL=legacy switches it off (A/B),
-    // RD_TEST_BUCKET_CAP makes the buckets small so that the fallback runs on ordinary inputs (test hook)
     {
-        // RD_TAIL_IMPL: unset = the one-launch tail (k_tail); "ordered" = round 3's four launches with the order and
-        // dedupe on the device; "legacy" = the unordered kernels + host ordering
+        // RD_TAIL_IMPL=legacy: the separate kernels (k_fixup, k_search, k_classify + k_rssi_u8) + host ordering instead
+        // of the one-launch tail (A/B; also what every shape other than the Davis one takes).  RD_TEST_BUCKET_CAP makes
+        // the per-stream match lists short so that the fallback runs on ordinary inputs (test hook)
         const char *ti = getenv("RD_TAIL_IMPL");
-        const bool legacy = (ti && ti[0] == 'l') || getenv("RD_SLICE_IMPL");  // (an explicit slice form means the unordered kernels)
-        b->ord_ok = !legacy && b->fast_ok && b->dc.S == 14 && b->dc.P == 16 && b->dc.K == 80 && b->dc.pre_mask == 0x91D3ull &&
-                    b->n_samples < (1l << 30) && b->dc.B < (1 << 24);
-        b->ft_ok = b->ord_ok && !(ti && ti[0] == 'o') && b->bits_stride % 4 == 0 && b->dc.L >= b->dc.B &&
+        const bool legacy = (ti && ti[0] == 'l') || getenv("RD_SLICE_IMPL");  // (an explicit slice form means the separate kernels)
+        b->ft_ok = !legacy && b->fast_ok && b->dc.S == 14 && b->dc.P == 16 && b->dc.K == 80 && b->dc.pre_mask == 0x91D3ull &&
+                   b->n_samples < (1l << 30) && b->dc.B < (1 << 24) && b->bits_stride % 4 == 0 && b->dc.L >= b->dc.B &&
                    (long)(b->n_blocks + 1) * b->dc.B - b->dc.L >= 0 &&   // (a batch shorter than a packet has no position to report)
                    ((long)(b->n_blocks + 1) * b->dc.B - b->dc.L) / 32 + 16 <= (long)b->bits_stride;
         if (const char *e = getenv("RD_TEST_BUCKET_CAP")) {
             const long v = atol(e);
-            if (v >= 1 && v < RD_BUCKET) { b->bucket_limit = (uint32_t)v; b->ft_limit = (uint32_t)v; }
+            if (v >= 1 && v < RD_BUCKET_MIN) b->ft_limit = (uint32_t)v;
         }
     }
-    {   // RD_FIXUP_IMPL=self: self-fix - the demod kernel's waves re-evaluate the groups they flagged themselves and no
-        // k_fixup is launched (a step is 6-13 us shorter, the demod kernel 4-14 us longer: profiles/r03_self_fix.txt;
-        // off by default because the roofline fraction is quoted on that kernel).  RD_TEST_SELF_PEND makes a wave's own
-        // list short so that its overflow into the global list - k_fixup after the run, search and slice again -
-        // happens on ordinary inputs (test hook)
-        const char *fi = getenv("RD_FIXUP_IMPL");
-        b->self_fix = b->fast_ok && fi && fi[0] == 's';
-        if (b->self_fix) b->ft_ok = false;  // (the opt-in forms of round 3 feed the four-launch tail)
-        if (const char *si = getenv("RD_SEARCH_IMPL")) if (si[0] == 'f') b->ft_ok = false;
-        if (const char *e = getenv("RD_TEST_SELF_PEND")) {
-            const long v = atol(e);
-            if (v >= 1 && v < 255) b->self_pend_limit = (uint32_t)v;
-        }
-    }
-    b->cnt_stride = RD_CNT_TOTAL + (b->ord_ok ? (((size_t)b->n_streams + 3) & ~(size_t)3) : 0);
+    b->cnt_stride = RD_CNT_TOTAL;
     if (b->ft_ok) {  // the groups' fix-up counters live behind the per-stream match counters: cleared with the set
         const size_t groups = ((size_t)b->n_streams + RD_FT_STREAMS - 1) / RD_FT_STREAMS;
         b->ft_cnt_off = b->cnt_stride;
@@ -346,34 +315,6 @@ static int batch_alloc(rd_batch *b) {
     }
     HIPCHK(hipMalloc(&b->d_cnt, 2 * b->cnt_stride * sizeof(uint32_t)));
     HIPCHK(hipMemset(b->d_cnt, 0, 2 * b->cnt_stride * sizeof(uint32_t)));
-    if (b->ord_ok) {
-        const size_t ns = (size_t)b->n_streams;
-        HIPCHK(hipMalloc(&b->ord.smatch, ns * RD_BUCKET * sizeof(int32_t)));
-        const size_t lists = (ns + RD_ORD_LIST_STREAMS - 1) / RD_ORD_LIST_STREAMS;
-        HIPCHK(hipMalloc(&b->ord.tasks, lists * RD_ORD_LIST_STREAMS * 2 * RD_BUCKET * RD_OTASK_BYTES));
-        HIPCHK(hipMalloc(&b->ord.wgtot, 2 * lists * sizeof(uint32_t)));
-    }
-    {   // RD_SEARCH_IMPL=fused: see the field's comment; whole tiles only, every reported position >= 0
-        const char *si = getenv("RD_SEARCH_IMPL");
-        b->fused = si && si[0] == 'f' && b->ord_ok && !b->self_fix && b->n_samples % RD_TILE_SAMPLES == 0 && b->dc.B <= b->dc.L;
-        if (b->fused) {
-            hipDeviceProp_t prop;
-            HIPCHK(hipGetDeviceProperties(&prop, b->device));
-            const size_t max_waves = (size_t)prop.multiProcessorCount * 8 * 4;  // the demod launch: at most 8 workgroups of 4 waves per CU
-            HIPCHK(hipMalloc(&b->d_wmatch, max_waves * RD_WAVE_MATCHES * sizeof(int2)));
-            HIPCHK(hipMalloc(&b->d_wcount, max_waves * sizeof(uint32_t)));
-            HIPCHK(hipMemset(b->d_wcount, 0, max_waves * sizeof(uint32_t)));
-            HIPCHK(hipMalloc(&b->d_extra, 2 * sizeof(rd_mf_extra)));
-            rd_mf_extra ex[2];
-            for (int k = 0; k < 2; k++) {
-                ex[k].wmatch = b->d_wmatch;
-                ex[k].wcount = b->d_wcount;
-                ex[k].p_hi = (int32_t)((long)(b->n_blocks + 1) * b->dc.B - b->dc.L);
-                ex[k].pad = 0;
-            }
-            HIPCHK(hipMemcpy(b->d_extra, ex, sizeof ex, hipMemcpyHostToDevice));
-        }
-    }
     HIPCHK(hipMalloc(&b->d_matches, (size_t)b->match_cap * sizeof(rd_match)));
     HIPCHK(hipMalloc(&b->d_recs, (size_t)b->rec_cap * sizeof(rd_packet)));
     HIPCHK(hipMalloc(&b->d_tasks, (size_t)b->rec_cap * RD_TASK_BYTES));
@@ -402,7 +343,6 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         hipFree(b->d_iq); hipFree(b->d_bits); hipFree(b->d_fix); hipFree(b->d_cnt);
         hipFree(b->d_matches); hipFree(b->d_recs); hipFree(b->d_tasks);
         hipFree(b->d_parsed);
-        hipFree(b->ord.smatch); hipFree(b->ord.tasks); hipFree(b->ord.wgtot); hipFree(b->d_extra); hipFree(b->d_wmatch); hipFree(b->d_wcount);
         hipFree(b->ft.fixb); hipFree(b->ft.gstate);
         hipHostFree(b->h_cnt_pin); hipHostFree(b->h_recs_pin);
         if (b->done) hipEventDestroy(b->done);
@@ -439,7 +379,7 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
         if (rc) return rc;
     }
     HIPCHK(hipMemcpy(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice));
-    if (!b->ft_sticky) b->ord_off = false;  // a new input: the tail with the order on the device gets its chance again
+    if (!b->ft_sticky) b->tail_off = false;  // a new input: the one-launch tail gets its chance again
     return RD_OK;
 }
 
@@ -451,7 +391,7 @@ static int batch_readback(rd_batch *b, hipEvent_t after) {
     HIPCHK(hipStreamWaitEvent(b->copy_stream, after, 0));
     HIPCHK(hipMemcpyAsync(b->h_cnt_pin, batch_cnt(b), RD_CNT_SLOTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
                           b->copy_stream));
-    const uint32_t spec = std::min(b->ord_run ? b->rec_cap : b->match_cap, b->spec_recs);
+    const uint32_t spec = std::min(b->dev_order ? b->rec_cap : b->match_cap, b->spec_recs);
     if (spec)
         HIPCHK(hipMemcpyAsync(b->h_recs_pin, b->d_recs, (size_t)spec * sizeof(rd_packet), hipMemcpyDeviceToHost,
                               b->copy_stream));
@@ -507,7 +447,7 @@ static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = fals
     // the run's last kernel carries the end-of-run event itself when nothing follows it
     hipEvent_t last = defer ? nullptr : b->run_timing ? b->ev[4] : b->kdone;
     if (b->run_timing && may_defer) b->ev_end.push_back(defer ? 0 : 1);
-    b->ord_run = false;
+    b->dev_order = false;
     if (b->ft_run && may_defer) {  // the run's first pass: everything behind the demod kernel in one launch
         rd_ft_bufs fb = b->ft;
         fb.fixcnt = batch_cnt(b) + b->ft_cnt_off;
@@ -516,24 +456,12 @@ static int batch_search_slice(rd_batch *b, hipStream_t st, bool may_defer = fals
                                             b->ft_limit ? b->ft_limit : fb.bcap, b->ft_seq, 0, b->d_recs, b->rec_cap, batch_cnt(b), st,
                                             last_on_slice ? last : nullptr, zero_next, (uint32_t)b->cnt_stride);
         if (!ok) return fail(RD_ERR_STATE, "the one-launch tail refused a shape its buffers were allocated for");
-        b->ord_run = true;   // (the records are final, as the ordered tail's)
+        b->dev_order = true;   // (the records are final: order and dedupe happened on the device)
         b->dense = 1;
-    } else if (b->ord_ok && !b->ord_off && !(b->run_timing && b->run_detail)) {
-        rd_ord_bufs ob = b->ord;
-        ob.scount = batch_cnt(b) + RD_CNT_TOTAL;
-        // fused search: on the run's first pass the demod kernel has filled the buckets and k_search_rem adds what it
-        // left out; a second pass (some list overflowed) searches in full, from cleared buckets
-        rd_rem_args rem = {b->d_wmatch, b->d_wcount, b->last_launch[1], b->last_launch[0], b->d_fix, b->fix_cap, b->last_fix};
-        const bool use_rem = b->fused_run && may_defer && b->last_launch[0] > 0;
-        b->ord_run = rd_launch_tail_ordered(lay, b->d_bits, b->bits_stride, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
-                                            b->dc, b->n_blocks, ob, b->bucket_limit, b->d_recs, b->rec_cap, batch_cnt(b), st,
-                                            last_on_slice ? last : nullptr, zero_next, (uint32_t)b->cnt_stride,
-                                            use_rem ? &rem : nullptr) != 0;
-        if (b->ord_run) b->dense = 1;  // one record per task from index 0 - and already in the final order
     }
-    if (!b->ord_run) {
+    if (!b->dev_order) {
         rd_launch_search(b->d_bits, b->bits_stride, b->n_streams, b->n_samples, B - L, (long)(b->n_blocks + 1) * B - L,
-                         b->dc, b->d_matches, b->match_cap, batch_cnt(b), st, nullptr, nullptr, zero_next, (uint32_t)b->cnt_stride);
+                         b->dc, b->d_matches, b->match_cap, batch_cnt(b), st);
         if (b->run_timing && b->run_detail) HIPCHK(hipEventRecord(b->ev[3], st));
         b->dense = rd_launch_slice(lay, b->d_bits, b->bits_stride, b->n_samples, b->dc, b->d_matches, b->match_cap, 1,
                                    b->n_blocks, 0, b->d_recs, nullptr, batch_cnt(b), st, last_on_slice ? last : nullptr,
@@ -598,26 +526,22 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
     }
     // a pipelined run waiting on this stream is adopted by this run's demod kernel (its stop event)
     const bool adopt = batch_stream_has_tail(b->device, st);
-    // (the fused search feeds the ordered tail's buckets: only when that tail is going to run)
-    const bool want_fused = b->fused && b->ord_ok && !b->ord_off && !(b->timing && b->timing_detail) && !b->parse;
     // the one-launch tail: the fix-up entries go to its workgroups' buckets
-    const bool want_ft = b->ft_ok && b->fast_ok && !b->ord_off && !(b->timing && b->timing_detail);
-    const uint32_t dflags = (b->self_fix ? RD_DEMOD_SELF_FIX : 0u) | (want_fused ? RD_DEMOD_FUSED_SEARCH : 0u) |
-                            (want_ft ? RD_DEMOD_FIX_BUCKETS : 0u);
-    const rd_mf_extra *extra = want_fused ? b->d_extra + b->cnt_set : nullptr;
+    const bool want_ft = b->ft_ok && b->fast_ok && !b->tail_off && !(b->timing && b->timing_detail);
+    const uint32_t dflags = want_ft ? RD_DEMOD_FIX_BUCKETS : 0u;
     uint32_t *fixl = want_ft ? b->ft.fixb : b->d_fix, *bcnt = want_ft ? cnt + b->ft_cnt_off : nullptr;
     const uint32_t fixc = want_ft ? b->ft.fix_bcap : b->fix_cap;
     uint32_t honoured = 0;
     if (b->timing && b->fast_ok) {
         // the demod kernel's dispatch carries its own start / stop events (no marker packets)
-        honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, b->ev[0], b->ev[1], dflags, b->self_pend_limit, extra, b->last_launch, bcnt);
+        honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, b->ev[0], b->ev[1], dflags, b->last_launch, bcnt);
         if (adopt && (rc = batch_adopt(b->device, st, b->ev[1]))) return rc;
     } else if (b->fast_ok && adopt) {
-        honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, nullptr, b->kfirst, dflags, b->self_pend_limit, extra, b->last_launch, bcnt);
+        honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, nullptr, b->kfirst, dflags, b->last_launch, bcnt);
         if ((rc = batch_adopt(b->device, st, b->kfirst))) return rc;
     } else {
         if (b->timing) HIPCHK(hipEventRecord(b->ev[0], st));
-        if (b->fast_ok) honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, nullptr, nullptr, dflags, b->self_pend_limit, extra, b->last_launch, bcnt);
+        if (b->fast_ok) honoured = rd_launch_demod(lay, fixl, fixc, cnt, st, nullptr, nullptr, dflags, b->last_launch, bcnt);
         if (b->timing) HIPCHK(hipEventRecord(b->ev[1], st));
         if (adopt) {  // (an event of THIS run: b->ev is null - or a finished run's - when the handle is untimed)
             hipEvent_t carrier = b->timing ? b->ev[1] : b->kfirst;
@@ -625,15 +549,13 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
             if ((rc = batch_adopt(b->device, st, carrier))) return rc;
         }
     }
-    // self-fix: the demod kernel's waves have patched their own words; the search kernel clears the next counter set
     b->second_pass = false;
-    b->self_run = b->fast_ok && (honoured & RD_DEMOD_SELF_FIX);
-    b->fused_run = b->fast_ok && (honoured & RD_DEMOD_FUSED_SEARCH);
     b->ft_run = b->fast_ok && (honoured & RD_DEMOD_FIX_BUCKETS);   // (k_tail does the fix-up and clears the next counter set)
-    if (!b->self_run && !b->ft_run)
-        rd_launch_fixup(lay, b->d_fix, b->fix_cap, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
+    if (!b->ft_run)   // (fixl / fixc: where this run's demod kernel put its list - the groups' bucket space when an ablated kernel
+                      // of the diagnostic library declined the buckets; bounded by fixc either way)
+        rd_launch_fixup(lay, fixl, fixc, cnt, b->fast_ok ? 0 : 1, cnt_next, st, (uint32_t)b->cnt_stride, b->last_fix);
     if (b->timing && b->timing_detail) HIPCHK(hipEventRecord(b->ev[2], st));
-    rc = batch_search_slice(b, st, true, (b->self_run || b->ft_run) ? cnt_next : nullptr);
+    rc = batch_search_slice(b, st, true, b->ft_run ? cnt_next : nullptr);
     if (rc) return rc;
     b->ran = true;
     return RD_OK;
@@ -660,7 +582,7 @@ static int batch_finish(rd_batch *b) {
             const rd_layout lay = batch_layout(b);
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
             b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
-            b->ord_off = true;
+            b->tail_off = true;
             b->h_cnt[RD_CNT_OVF] = 0;
             b->h_cnt[RD_CNT_FIX] = 0;
             redo_search = true;
@@ -676,30 +598,21 @@ static int batch_finish(rd_batch *b) {
             const rd_layout lay = batch_layout(b);
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
             // mark handled: neither this branch nor the self-fix one below may see the count again
-            uint32_t cap = b->self_run ? 0u : b->fix_cap;
+            uint32_t cap = b->fix_cap;
             HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
             b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
             redo_search = true;
-        } else if (b->self_run && b->h_cnt[RD_CNT_FIX] > 0) {
-            // self-fix run whose waves listed more words than they keep (quiet or degenerate input; RD_TEST_SELF_PEND):
-            // those went to the global list - k_fixup now, then search and slice again on the patched bits
-            const rd_layout lay = batch_layout(b);
-            rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 0, nullptr, st);
-            const uint32_t zero = 0;  // mark handled (k_fixup has read the count by the time this copy runs: same stream)
-            HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &zero, sizeof zero, hipMemcpyHostToDevice, st));
-            b->last_fix = (uint64_t)b->h_cnt[RD_CNT_FIX] + b->h_cnt[RD_CNT_SELF];
-            redo_search = true;
         } else if (attempt == 0) {
-            b->last_fix = (uint64_t)b->h_cnt[RD_CNT_FIX] + (b->self_run ? b->h_cnt[RD_CNT_SELF] : 0u);
+            b->last_fix = (uint64_t)b->h_cnt[RD_CNT_FIX];
         }
-        if (redo_search && b->ord_off) b->ord_run = false;  // (the bucket-overflow branch above: not the record-overflow one below)
-        if (b->ord_run && b->h_cnt[RD_CNT_OVF]) {
-            // a stream with more matches than its bucket holds (or more records than the list): this input goes
-            // through the unordered kernels and the host-side ordering, now and until the next upload
-            b->ord_off = true;
+        if (redo_search && b->tail_off) b->dev_order = false;  // (the bucket-overflow branch above: not the record-overflow one below)
+        if (b->dev_order && b->h_cnt[RD_CNT_OVF]) {
+            // a stream with more matches than its list holds (or more records than the output array): this input goes
+            // through the separate kernels and the host-side ordering, now and until the next upload
+            b->tail_off = true;
             if (dbg_host())
-                fprintf(stderr, "[rd] ordered tail overflow: flags %u (1 bucket, 2 records, 4 a demod wave's match list: %u entries), matches %u, fused %d\n",
-                        b->h_cnt[RD_CNT_OVF], b->h_cnt[RD_CNT_SLOTS - 1], b->h_cnt[RD_CNT_MATCH], (int)b->fused_run);
+                fprintf(stderr, "[rd] one-launch tail overflow: flags %u (1 a stream's match list, 2 records), matches %u\n",
+                        b->h_cnt[RD_CNT_OVF], b->h_cnt[RD_CNT_MATCH]);
             const uint32_t zero[5] = {0, 0, 0, 0, 0};  // matches, boundary records, tasks, parsed, overflow
             HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
             b->second_pass = true;
@@ -707,7 +620,7 @@ static int batch_finish(rd_batch *b) {
             if (rc2) return rc2;
             continue;
         }
-        if (!b->ord_run && b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
+        if (!b->dev_order && b->h_cnt[RD_CNT_MATCH] > b->match_cap) {
             // every pointer is cleared as it is freed: should one of the allocations below fail, rd_batch_destroy
             // must not free anything twice (and the handle reports the failure on every later call)
             hipFree(b->d_matches); b->d_matches = nullptr;
@@ -738,9 +651,6 @@ static int batch_finish(rd_batch *b) {
         }
         const uint32_t zero[5] = {0, 0, 0, 0, 0};  // matches, boundary records, tasks, parsed, overflow flags
         HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_MATCH, zero, sizeof zero, hipMemcpyHostToDevice, st));
-        // (the ordered tail's per-stream match counts hold the first pass's matches: its search starts from zero again)
-        if (b->ord_ok && b->cnt_stride > RD_CNT_TOTAL)
-            HIPCHK(hipMemsetAsync(batch_cnt(b) + RD_CNT_TOTAL, 0, (b->cnt_stride - RD_CNT_TOTAL) * sizeof(uint32_t), st));
         b->second_pass = true;
         int rc2 = batch_search_slice(b, st);
         if (rc2) return rc2;
@@ -759,7 +669,7 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     // sparse layout: one slot per match + the block-boundary twins behind match_cap; dense: one record per task
     const uint32_t nprim = b->dense ? std::min(b->h_cnt[RD_CNT_TASKS], b->rec_cap) : std::min(b->h_cnt[RD_CNT_MATCH], b->match_cap);
     const uint32_t nextra = b->dense ? 0u : std::min(b->h_cnt[RD_CNT_REC], b->match_cap);
-    const uint32_t have = std::min(b->ord_run ? b->rec_cap : b->match_cap, b->spec_recs);
+    const uint32_t have = std::min(b->dev_order ? b->rec_cap : b->match_cap, b->spec_recs);
     // Late copies go to the copy stream: it has already waited for this run's last kernel, whereas the
     // launch stream may hold the NEXT batch's run by now (two resident batches alternate in bench.py) and a
     // copy queued there would wait for it.
@@ -774,7 +684,7 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
     const uint32_t nrec = nprim + nextra;
     b->spec_recs = std::max<uint32_t>(1024, nprim + nprim / 4);
     const double t2 = now_ms();
-    if (b->ord_run) {  // the device wrote them in the reference's order, duplicates dropped: copy, nothing else
+    if (b->dev_order) {  // the device wrote them in the reference's order, duplicates dropped: copy, nothing else
         *n = (int)nrec;
         if ((int)nrec > cap) return fail(RD_ERR_CAPACITY, "need room for %u packets", nrec);
         if (nrec) {
@@ -939,8 +849,7 @@ extern "C" int rd_batch_last_run_forms(rd_batch *b, uint32_t *forms) {
     if (!b || !forms) return fail(RD_ERR_ARG, "null argument");
     int rc = batch_finish(b);
     if (rc) return rc;
-    *forms = (b->ord_run ? RD_FORM_ORDERED_TAIL : 0u) | (b->ft_run && b->ord_run ? RD_FORM_ONE_LAUNCH_TAIL : 0u) | (b->self_run ? RD_FORM_SELF_FIX : 0u) |
-             (b->fused_run && !b->second_pass ? RD_FORM_FUSED_SEARCH : 0u) | (b->second_pass ? RD_FORM_SECOND_PASS : 0u);
+    *forms = (b->dev_order ? RD_FORM_ORDERED_TAIL | RD_FORM_ONE_LAUNCH_TAIL : 0u) | (b->second_pass ? RD_FORM_SECOND_PASS : 0u);
     return RD_OK;
 }
 
@@ -1003,6 +912,10 @@ struct rd_demod {
     bool one_ok = false;            // the configuration is one k_stream_block is built for (and RD_STREAM_IMPL != legacy)
     uint32_t seq = 0;               // blocks sent through k_stream_block
     std::vector<rd_packet> gather;  // records of a one-launch block, streams one after the other
+    // A producer's buffer registered with the device (rd_demod_register_input): rd_demod_submit_from launches on blocks
+    // that already lie there - a shared-memory ring an SDR process fills - without copying them anywhere
+    uint8_t *ext_host = nullptr, *ext_dev = nullptr;
+    size_t ext_bytes = 0;
     int stale = 0;                  // blocks in flight whose fetch timed out: dropped (waited for, results discarded) by
                                     // the next submit / reset - the caller has already been told (worker.py:56-58)
 };
@@ -1067,7 +980,30 @@ static int demod_alloc(rd_demod *h) {
     }
     HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
+    // Nothing is allocated inside a demodulate() call: the complex ring of a single-stream handle exists from the start
+    // (pyrtlsdr feeds complex blocks), and the state mirrors' float64 kernels run once here - the first launch of a
+    // kernel that needs scratch memory costs milliseconds, which `.discriminated` (read by protocol.py:307-309 for the
+    // first CRC-valid packet) used to pay inside a 30 ms block budget.
+    if (NS == 1) {
+        HIPCHK(hipMalloc(&h->d_cring, 2 * (16 + 2 * B) * sizeof(double)));
+        HIPCHK(hipMemset(h->d_cring, 0, 2 * (16 + 2 * B) * sizeof(double)));
+    }
     HIPCHK(hipDeviceSynchronize());  // the memsets above ran on the null stream
+    {
+        rd_layout wl;
+        wl.iq = h->d_ring + 32 + 2 * B; wl.stream_stride = h->ring_stride; wl.n_streams = (int)NS; wl.n_samples = (uint32_t)B;
+        wl.hist_mode = 0; wl.valid_from = 0; wl.bits = h->d_blockbits; wl.bits_stride = (B + 31) / 32;
+        rd_launch_disc(wl, 0, 0, 8, h->d_tmp, h->st);
+        rd_launch_filtered(wl, 0, 0, 8, h->d_tmp, h->st);
+        if (h->d_cring) {
+            rd_cplx_layout cl;
+            cl.x = h->d_cring + 2 * (16 + B); cl.valid_from = 0; cl.n = (long)B;
+            rd_launch_cplx_disc(cl, 0, 8, h->d_tmp, h->st);
+            rd_launch_cplx_filtered(cl, 0, 8, h->d_tmp, h->st);
+        }
+        HIPCHK(hipMemcpyAsync(h->h_tmp, h->d_tmp, 64, hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+    }
     {   // one launch per block where the kernel exists for the configuration; RD_STREAM_IMPL=legacy: the multi-launch form (A/B)
         const char *e = getenv("RD_STREAM_IMPL");
         const rd_devcfg &c = h->dc;
@@ -1084,6 +1020,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         if (h->device >= 0) hipSetDevice(h->device);
         if (h->st) hipStreamSynchronize(h->st);
         if (h->st_copy) hipStreamSynchronize(h->st_copy);
+        if (h->ext_host) hipHostUnregister(h->ext_host);
         hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_tmp);
@@ -1208,7 +1145,7 @@ static rd_cplx_layout demod_clayout(const rd_demod *h, long seen_before) {
 // keeps in raw_samples) so history carries over exactly.
 static int demod_enter_cplx(rd_demod *h) {
     const size_t B = (size_t)h->dc.B;
-    if (!h->d_cring) HIPCHK(hipMalloc(&h->d_cring, 2 * (16 + 2 * B) * sizeof(double)));
+    if (!h->d_cring) HIPCHK(hipMalloc(&h->d_cring, 2 * (16 + 2 * B) * sizeof(double)));  // (single-stream handles have it from demod_alloc)
     rd_launch_lut(h->d_ring, h->d_cring, 16 + 2 * B, h->st);
     HIPCHK(hipGetLastError());
     h->cplx_mode = true;
@@ -1218,7 +1155,8 @@ static int demod_enter_cplx(rd_demod *h) {
 // Queue one block per stream (uint8: NS x 2B bytes, stream-major; complex128: single stream only): the
 // copy to the device on the copy stream, everything else behind it on the compute stream.  Returns at
 // once; at most two blocks may be in flight.
-static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
+// `ext_off` >= 0: the block lies at that offset of the registered producer buffer (no copy: the kernels read it there)
+static int demod_submit(rd_demod *h, const void *samples, int is_complex, long ext_off = -1) {
     const size_t B = (size_t)h->dc.B, L = (size_t)h->dc.L, NS = (size_t)h->NS;
     const size_t bw = (B + 31) / 32, lw = (L + 31) / 32;
     int rc = demod_alloc(h);
@@ -1228,8 +1166,46 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
     rd_slot &sl = h->slot[(h->head + h->nflight) & 1];
     hipStream_t st = h->st;
     const size_t nbytes = is_complex ? 2 * B * sizeof(double) : NS * 2 * B;
-    memcpy(sl.h_in, samples, nbytes);
+    const uint8_t *in_host = sl.h_in, *in_dev = sl.d_in_map;   // where this block's bytes are, host and device address
+    if (ext_off >= 0) {
+        in_host = h->ext_host + ext_off;
+        in_dev = h->ext_dev + ext_off;
+    } else {
+        memcpy(sl.h_in, samples, nbytes);
+    }
     sl.one = false;
+    if (h->one_ok && NS == 1 && h->dc.B <= 8192 && (is_complex || h->cplx_mode)) {
+        // ONE launch for the complex-input branch as well (py:144-150: what pyrtlsdr's stream() feeds the live receiver,
+        // /root/reference/src/rtldavis/runners/rtlsdr.py:100-103); a uint8 block on a handle in complex mode goes through
+        // the LUT inside the kernel.  The first complex block converts the byte ring once (py:26,38-39: history carries over)
+        if (!h->cplx_mode) {
+            rc = demod_enter_cplx(h);
+            if (rc) return rc;
+        }
+        rd_sbc_args a;
+        a.cfg = h->dc;
+        a.ring = h->d_cring;
+        a.in = in_dev;
+        a.in_is_u8 = is_complex ? 0 : 1;
+        const int nw = h->cur_win ^ 1;
+        a.win_in = h->d_win[h->cur_win];
+        a.win_out = h->d_win[nw];
+        a.recs_host = sl.d_recs_map;
+        a.cnt_host = sl.d_sb_map;
+        a.flag_host = sl.d_sb_map + NS;
+        a.seq = ++h->seq;
+        a.seen_before = h->seen;
+        if (rd_launch_stream_block_cplx(a, st)) {
+            HIPCHK(hipGetLastError());
+            h->cur_win = nw;
+            sl.seq = a.seq;
+            sl.one = true;
+            h->seen++;
+            h->nflight++;
+            return RD_OK;
+        }
+        --h->seq;
+    }
     if (h->one_ok && !is_complex && !h->cplx_mode) {
         // ONE launch: the kernel takes the block from the pinned buffer, rolls the ring, decides the bits exactly,
         // searches, slices and leaves records, counts and a per-stream sequence number in mapped host memory
@@ -1237,7 +1213,7 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
         a.cfg = h->dc;
         a.ring = h->d_ring;
         a.ring_stride = h->ring_stride;
-        a.in = sl.d_in_map;
+        a.in = in_dev;
         const int nw = h->cur_win ^ 1;
         a.win_in = h->d_win[h->cur_win];
         a.win_out = h->d_win[nw];
@@ -1257,7 +1233,7 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex) {
         }
         --h->seq;
     }
-    HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, nbytes, hipMemcpyHostToDevice, h->st_copy));
+    HIPCHK(hipMemcpyAsync(sl.d_in, in_host, nbytes, hipMemcpyHostToDevice, h->st_copy));
     HIPCHK(hipEventRecord(sl.e_in, h->st_copy));
     HIPCHK(hipStreamWaitEvent(st, sl.e_in, 0));
     if (is_complex && !h->cplx_mode) {
@@ -1375,6 +1351,49 @@ extern "C" int rd_demod_submit(rd_demod *h, const void *samples, size_t count, i
         if (h->cplx_mode && NS != 1) return fail(RD_ERR_STATE, "handle is in complex mode: reset() first");
     }
     return demod_submit(h, samples, is_complex);
+}
+
+// Zero-copy input (the pinned ring that replaces the pickled-ndarray queue hop,
+// /root/reference/src/rtldavis/runners/rtlsdr.py:100-103 -> /root/reference/src/rtldavis/worker.py:37).
+extern "C" int rd_demod_register_input(rd_demod *h, void *host, size_t nbytes) {
+    if (!h) return fail(RD_ERR_ARG, "null handle");
+    int rc = demod_alloc(h);
+    if (rc) return rc;
+    if (h->nflight) return fail(RD_ERR_STATE, "%d block(s) in flight: fetch them before the input buffer changes", h->nflight);
+    if (h->ext_host) {
+        HIPCHK(hipHostUnregister(h->ext_host));
+        h->ext_host = h->ext_dev = nullptr;
+        h->ext_bytes = 0;
+    }
+    if (!host || nbytes == 0) return RD_OK;  // (unregister only)
+    if ((uintptr_t)host % 16) return fail(RD_ERR_ARG, "the input buffer must be 16-byte aligned");
+    HIPCHK(hipHostRegister(host, nbytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    void *dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e != hipSuccess) {
+        hipHostUnregister(host);
+        return fail(RD_ERR_DEVICE, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+    }
+    h->ext_host = (uint8_t *)host;
+    h->ext_dev = (uint8_t *)dev;
+    h->ext_bytes = nbytes;
+    return RD_OK;
+}
+
+extern "C" int rd_demod_submit_from(rd_demod *h, size_t offset, size_t count, int is_complex) {
+    if (!h) return fail(RD_ERR_ARG, "null handle");
+    if (!h->ext_host) return fail(RD_ERR_STATE, "no input buffer registered (rd_demod_register_input)");
+    const size_t B = (size_t)h->dc.B, NS = (size_t)h->NS;
+    size_t want = 0;
+    if (is_complex && NS != 1) return fail(RD_ERR_STATE, "complex input needs a single-stream handle");
+    if (rd_check_block_count(is_complex, count, B, NS, &want) != RD_OK)
+        return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu, expected %zu", count, want);  // py:32-36 / py:145-149
+    if (!is_complex && h->cplx_mode && NS != 1) return fail(RD_ERR_STATE, "handle is in complex mode: reset() first");
+    const size_t nbytes = is_complex ? 2 * B * sizeof(double) : NS * 2 * B;
+    if (offset % 16 || offset > h->ext_bytes || nbytes > h->ext_bytes - offset)
+        return fail(RD_ERR_ARG, "block at offset %zu (%zu bytes) does not lie 16-byte aligned inside the registered buffer (%zu bytes)",
+                    offset, nbytes, h->ext_bytes);
+    return demod_submit(h, nullptr, is_complex, (long)offset);
 }
 
 extern "C" int rd_demod_fetch(rd_demod *h, rd_packet *out, int cap, int *n) {

@@ -1,21 +1,21 @@
 // rd_demod_mfma.hip - k_demod_mfma: the fused IQ -> sign-bit kernel with the FIR on the matrix pipe.
 //
-// Same contract as k_demod_bits (rd_kernels.hip): reads lay.iq once, writes the packed sign bits and
-// appends the 8-sample groups whose sign is not certain to the fix-up list (k_fixup re-evaluates those
-// exactly).  Reference stages: LUT py:38-39 + rotate_fs4 py:46-49 + fir9 py:71-73 + discriminate
-// numerator py:89 + quantize py:98 (py = /root/reference/src/rtldavis/dsp.py).  Arithmetic and its
-// error bound: rd_mfma.h.
+// Reads lay.iq once, writes the packed sign bits and lists the 8-sample groups whose sign is not certain (the tail
+// re-evaluates those exactly: k_tail / k_fixup in rd_kernels.hip).  Reference stages: LUT py:38-39 + rotate_fs4
+// py:46-49 + fir9 py:71-73 + discriminate numerator py:89 + quantize py:98 (py = /root/reference/src/rtldavis/dsp.py).
+// Arithmetic and its error bound: rd_mfma.h.
 //
-// One wave = one 2048-sample tile per iteration.  Column n = lane & 31 owns samples a0 .. a0+63
-// (a0 = tile + 64 n), its window is the 144 bytes from 16 bytes before them; lane half h = lane >> 5
-// supplies bytes 8h..8h+7 of every 16-byte k-step of that window and receives, per 16-output block
-// b = 0..3, re/im of g[a0 + 16 b + 8 h + 1 + r], r = 0..7.  A lane therefore decides the eight signs
-// of the aligned group [a0 + 16 b + 8 h, +8): six numerators from its own registers, the first two
-// with g[base-1], g[base] of the lane that precedes it in time (other half, same or previous block;
-// for block 0 of half 0 the last block of the previous column), exchanged through a per-wave LDS
-// buffer.  A wave works through `chunk` consecutive tiles so that the very first group of a tile finds
-// its predecessors in the previous iteration; at the start of a chunk (and of a stream) that one
-// group is put on the fix-up list instead.
+// One wave = one 2048-sample tile per iteration.  Column n = lane & 31 owns samples a0 .. a0+63 (a0 = tile + 64 n), its
+// window is the 144 bytes from 16 bytes before them; lane half h = lane >> 5 supplies bytes 8h..8h+7 of every 16-byte
+// k-step of that window.  The 8-output formulation of rd_mfma.h: per block b = 0..7 a lane receives re / im (both tap
+// digits) of g[a0 + 8 b + 4 h + 1 + r'], r' = 0..3, and decides the four signs of t = base .. base + 3,
+// base = a0 + 8 b + 4 h: two numerators from its own outputs, two with g[base - 1], g[base] of the lane that precedes
+// it in time, exchanged through a per-wave LDS buffer.  A wave works through chunks of consecutive tiles so that a
+// tile's first group finds its predecessors in the previous iteration; at the start of a chunk (and of a stream)
+// that one group is listed for the exact pass instead.
+// The forms this file used to carry beside this one - the 16-output formulation (24 MFMAs per tile), two image buffers,
+// software-pipelined blocks, the in-kernel preamble search and the self-fix variant - lost their A/B runs
+// (docs/history/r03.md, profiles/r03_*) and live in the git history (b326bb2 and before).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,8 +44,7 @@
 // predecessor exchange: three buffers of 64 x 16 B, then two carry slots (tile parity)
 // + the offset constant (four copies); a multiple of 32 so that XOR 16 toggles between the two carry slots
 #define RD_MF_XB_BYTES (3 * 1024 + 32 + 32)
-#define RD_MF_PEND 32        // entries a wave keeps before it appends them to the global list
-#define RD_MF_PEND_SELF 64   // ... in the self-fix variant (RD_OPT_SELF), which re-evaluates them itself at its end
+#define RD_MF_PEND 32        // entries a wave keeps before it appends them to the list (or to the groups' buckets)
 // tiles whose words are stored together (a multiple of 4 that divides the default chunk)
 #ifndef RD_MF_STAGE_TILES
 #define RD_MF_STAGE_TILES 4
@@ -58,8 +57,7 @@ typedef uint32_t rd_u4v __attribute__((ext_vector_type(4)));
 typedef float rd_f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t rd_u2v __attribute__((ext_vector_type(2)));
 
-__device__ const rd_mf_taps g_mf_taps = rd_mf_make_taps();
-static const rd_mf_taps h_mf_taps = rd_mf_make_taps();
+static const rd_mf_taps h_mf_taps = rd_mf_make_taps();   // (the 16-output tap matrix: the RSSI windows of rd_kernels.hip use it)
 __device__ const rd_mf_taps8 g_mf_taps8 = rd_mf_make_taps8();
 static const rd_mf_taps8 h_mf_taps8 = rd_mf_make_taps8();
 extern "C" void rd_debug_mfma_taps8(uint16_t *out) { memcpy(out, &h_mf_taps8, sizeof h_mf_taps8); }
@@ -88,11 +86,6 @@ __device__ __forceinline__ float rd_mf_num(float ar, float ai, float cr, float c
 // samples and one fma per group instead of an fma per sample.
 __device__ __forceinline__ float rd_mf_guard(float nmin, float tmax) { return __builtin_fmaf(-4.76837158e-7f, tmax, nmin); }
 // min(m, a, b) without abs (r may be negative: then the group is inside the band anyway)
-__device__ __forceinline__ float rd_min3(float m, float a, float b) {
-    float o;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(m), "v"(a), "v"(b));
-    return o;
-}
 
 
 // LDS traffic of the predecessor exchange and of the pending list goes through inline asm: the compiler
@@ -126,14 +119,6 @@ __device__ __forceinline__ uint32_t rd_lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
-struct rd_mf_state {
-    uint32_t W;       // sign bits of blocks 1-3 (24), first sample at the top
-    uint32_t w0;      // the six own sign bits of block 0
-    uint32_t fbytes;  // byte b != 0: block b's group is inside the guard band
-    bool slow;        // wave-uniform: some block of the tile took the second-level test (fbytes may be set)
-    float g0r, g0i;   // block 0's first output: its two boundary numerators come last
-};
-
 // Guard band in two steps (bound: rd_mfma.h).  Per sample r = |num| - 2^-21 |b d| takes care of the part of
 // the error that scales with the products; what is left, 4 E0 F + const, needs F = the largest |component|
 // involved.  The common path compares a group's min r with that term at F = the largest |g| ANY input can
@@ -142,144 +127,10 @@ struct rd_mf_state {
 // hand (v_max3 over the block) and the test repeated with it.
 __device__ __forceinline__ bool rd_mf_any(bool c) { return __ballot(c) != 0; }
 
-// One 16-output block of the tile in three parts: rd_mf_burst (fragments + 6 MFMAs), rd_mf_combine (the two digits
-// -> g) and rd_mf_tail (this lane's group of 8 signs, guard band, predecessor exchange).  RD_OPT_PIPE issues block
-// B+1's burst BEFORE block B's tail, so that a wave's own vector work runs under its own MFMAs instead of the wave
-// sitting out the ~200 cycles until the burst's results are back (the other waves of the SIMD are as often as not
-// waiting for memory).
-// xw + WOFF: LDS address this lane's (g6, g7) go to; xr: where its predecessors' are.
-template <int B, int DBG>
-__device__ __forceinline__ void rd_mf_burst(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_u2v (&D)[9],
-                                            rd_h8 (&bf)[3], uint32_t dc_addr, rd_f16v &ah, rd_f16v &al) {
-    const rd_f16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // the hi accumulator starts at -D_hi in all sixteen positions (four broadcast reads, in flight under
-    // the fragment preparation)
-    rd_f4v c0, c1, c2, c3;
-    if (DBG != 4 && DBG != 10)
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4"
-                     : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(dc_addr) : "memory");
-    // fragments of k-steps 2B, 2B+1, 2B+2 of the window: the first one is the previous block's last
-    if (B == 0) bf[0] = rd_mf_frag(D[0]); else bf[0] = bf[2];
-    bf[1] = rd_mf_frag(D[2 * B + 1]);
-    bf[2] = rd_mf_frag(D[2 * B + 2]);
-    if (DBG == 4 || DBG == 10) {  // ablation: no matrix pipe, the vector work on stand-in values
-        const rd_u4v q0 = __builtin_bit_cast(rd_u4v, bf[0]), q1 = __builtin_bit_cast(rd_u4v, bf[1]),
-                     q2 = __builtin_bit_cast(rd_u4v, bf[2]);
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            ah[i] = __builtin_bit_cast(float, (i & 8 ? q1 : q0)[i & 3] | 0x3f000000u) + (float)i;
-            al[i] = __builtin_bit_cast(float, (i & 8 ? q2 : q1)[i & 3] | 0x3f000000u);
-        }
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory");
-        const rd_f16v dc = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
-        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[0], bf[0], dc, 0, 0, 0);  // C = -D_hi: the -127.4 offset
-        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[0], bf[0], zero, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[1], bf[1], ah, 0, 0, 0);
-        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[1], bf[1], al, 0, 0, 0);
-        if (DBG != 9) {  // (9: a third fewer MFMAs, wrong results - what the matrix pipe costs in clock and time)
-            ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[2], bf[2], ah, 0, 0, 0);
-            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[2], bf[2], al, 0, 0, 0);
-        }
-    }
-}
-
-// g[2r], g[2r+1] = re, im of output r of this lane's group
-__device__ __forceinline__ void rd_mf_combine(const rd_f16v &ah, const rd_f16v &al, float (&g)[16]) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) g[i] = __builtin_fmaf(ah[i], 2048.0f, al[i]);
-}
-
-template <int B, int DBG, int WOFF>
-__device__ __forceinline__ void rd_mf_tail(const float (&g)[16], uint32_t xw, uint32_t xr, rd_mf_state &st, float *dg,
-                                           int dleft) {
-    if (DBG == 3) {
-#pragma unroll
-        for (int r = 0; r < 8; r++)  // the tile's last output (column 31, half 1, r = 7) belongs to the next tile
-            if (16 * B + r < dleft) { dg[2 * (16 * B + r)] = g[2 * r]; dg[2 * (16 * B + r) + 1] = g[2 * r + 1]; }
-    }
-    {
-        const rd_f4v x = {g[12], g[13], g[14], g[15]};
-        rd_lds_write16<WOFF>(xw, x);
-    }
-    rd_f4v p = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (B > 0) p = rd_lds_read16<0>(xr);  // g[base-1], g[base]: in flight under the group's own work
-    float nmin = 3.0e38f, tmax = 0.0f;
-    float num[6];  // the six numerators of this lane's own outputs
-#pragma unroll
-    for (int q = 2; q < 8; q += 2) {
-        float ta, tb;
-        num[q - 2] = rd_mf_num(g[2 * q - 4], g[2 * q - 3], g[2 * q - 2], g[2 * q - 1], ta);
-        num[q - 1] = rd_mf_num(g[2 * q - 2], g[2 * q - 1], g[2 * q], g[2 * q + 1], tb);
-        nmin = rd_min3abs(nmin, num[q - 2], num[q - 1]);
-        tmax = rd_max3abs(tmax, ta, tb);
-    }
-    // Signs: ONE shift chain per word, in time order, one v_alignbit per sample and nothing else (separate
-    // partial words shifted and OR-ed together afterwards cost three more instructions per block, and every
-    // instruction that is not an f32 multiply / add costs a SIMD 4.5 cycles here).  Blocks 1-3 go into st.W
-    // behind the wait for their predecessors; block 0's own six go into st.w0 and are completed, with the two
-    // numerators that need the previous column's last outputs, at the end of the tile.
-    if (B == 0) {
-        st.g0r = g[0]; st.g0i = g[1];
-        uint32_t w = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) w = rd_shift_in_sign(w, num[i]);
-        st.w0 = w;
-        st.W = 0;
-    } else {
-        rd_lds_wait(p);
-        float t0, t1;
-        const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, t0);
-        const float n1 = rd_mf_num(p.z, p.w, g[0], g[1], t1);
-        nmin = rd_min3abs(nmin, n0, n1);
-        tmax = rd_max3abs(tmax, t0, t1);
-        uint32_t w = rd_shift_in_sign(st.W, n0);
-        w = rd_shift_in_sign(w, n1);
-#pragma unroll
-        for (int i = 0; i < 6; i++) w = rd_shift_in_sign(w, num[i]);
-        st.W = w;
-    }
-    if (DBG == 0 || DBG == 3) {
-        const float nm = rd_mf_guard(nmin, tmax);
-        if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {  // rare; NaN counts as inside
-            st.slow = true;
-            float F = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 8; r++) F = rd_max3abs(F, g[2 * r], g[2 * r + 1]);
-            if (B > 0) {
-                F = rd_max3abs(F, p.x, p.y);
-                F = rd_max3abs(F, p.z, p.w);
-            }
-            if (!(nm > rd_mf_c0(F))) st.fbytes |= 1u << (8 * B);
-        }
-    }
-}
-
-// burst + combine + tail of one block, one after the other (the order without RD_OPT_PIPE).  The six MFMAs go out as
-// one burst with no vector instruction between them: a wave then sits in the matrix pipe's queue for ~192 cycles
-// while the other waves of the SIMD issue their VALU work, instead of every wave stalling at an MFMA every few
-// instructions (in-order issue).
-template <int B, int DBG, int WOFF>
-__device__ __forceinline__ void rd_mf_block(const rd_h8 (&Ahi)[3], const rd_h8 (&Alo)[3], const rd_u2v (&D)[9],
-                                            rd_h8 (&bf)[3], uint32_t dc_addr, uint32_t xw, uint32_t xr,
-                                            rd_mf_state &st, float *dg, int dleft) {
-    rd_f16v ah, al;
-    __builtin_amdgcn_sched_barrier(0);
-    rd_mf_burst<B, DBG>(Ahi, Alo, D, bf, dc_addr, ah, al);
-    __builtin_amdgcn_sched_barrier(0);
-    if (DBG == 5 || DBG == 11) {  // ablation: the matrix pipe with next to no vector work behind it
-        st.W ^= __builtin_bit_cast(uint32_t, ah[0] + al[15]);
-        return;
-    }
-    float g[16];
-    rd_mf_combine(ah, al, g);
-    rd_mf_tail<B, DBG, WOFF>(g, xw, xr, st, dg, dleft);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
-// RD_OPT_B8: the 8-output formulation of rd_mfma.h - 16 MFMAs per tile instead of 24 (a matrix instruction in flight
-// slows the vector issue of the whole SIMD: with a third fewer of them the same vector work gets through sooner).
-// Lane (n, h), block b = 0..7: re / im of g[a0 + 8 b + 4 h + 1 + r'], r' = 0..3 - it decides the four signs of
+// The 8-output formulation of rd_mfma.h: 16 MFMAs per tile (a matrix instruction in flight slows the vector issue of the
+// whole SIMD).  Lane (n, h), block b = 0..7: re / im of g[a0 + 8 b + 4 h + 1 + r'], r' = 0..3 - it decides the four signs of
 // t = base .. base + 3 (base = a0 + 8 b + 4 h): two from its own outputs, two with g[base - 1], g[base] of the lane
 // that precedes it in time ((n, 0, b) for h = 1, (n, 1, b - 1) for h = 0, (n - 1, 1, 7) for block 0 of half 0, the
 // previous tile's lane 63 for lane 0).  Those two are FINISHED one block later, under the next block's MFMAs: the
@@ -487,37 +338,8 @@ __device__ __forceinline__ void rd_mf_flush(const uint32_t *pend, uint32_t count
 // of a stream, the occasional group inside the guard band): one pass, ~1 % of the wave's instructions, instead of a
 // kernel launch whose 18 us are a launch and two dependent memory latencies.  The wave's word stores are waited for
 // first; the entries name words of the wave's own tiles only.  `noinline`: the float64 path's registers are needed
-// when the tile loop's are dead, and must not become part of the loop's allocation.
-__device__ __attribute__((noinline)) void rd_mf_selffix(uint32_t pend_addr, uint32_t count, rd_layout lay, uint32_t *self_counter) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const uint32_t lane = (uint32_t)rd_lane_now();
-    if (lane < count) {
-        const uint32_t e = rd_lds_read4(pend_addr + 4 * lane);
-        const uint32_t widx = e >> 4;
-        const uint32_t s = widx / (uint32_t)lay.bits_stride;
-        const uint32_t run = widx - s * (uint32_t)lay.bits_stride;
-        const uint8_t *base = lay.iq + (size_t)s * lay.stream_stride;
-        for (int g = 0; g < RD_GROUPS; g++) {
-            if (!((e >> g) & 1)) continue;
-            const long t0 = (long)run * RD_RUN + g * RD_GROUP;
-            const long left = (long)lay.n_samples - t0;
-            if (left <= 0) break;
-            const int cnt = left < RD_GROUP ? (int)left : RD_GROUP;
-            // samples t0-10 .. t0+9 = ten dwords at a 4-byte aligned address; those wholly outside the readable
-            // input are not touched (k_fixup's rule)
-            const uint8_t *p = base + 2 * (t0 - 10);
-            const long x = lay.valid_from - (t0 - 10), z = (long)lay.n_samples + 8 - (t0 - 10);
-            const int d_lo = x <= 0 ? 0 : x >= 20 ? 10 : (int)(x / 2);
-            const int d_hi = z <= 0 ? 0 : z >= 20 ? 10 : (int)((z + 1) / 2);
-            uint32_t dw[10];
-#pragma unroll
-            for (int d = 0; d < 10; d++) dw[d] = (d >= d_lo && d < d_hi) ? *(const uint32_t *)(p + 4 * d) : 0u;
-            ((uint8_t *)lay.bits)[(size_t)widx * 4 + g] = (uint8_t)rd_exact_group_dw(dw, t0, cnt, lay.valid_from);
-        }
-    }
-    if (lane == 0) atomicAdd(self_counter, count);
-}
 
+// Store the staged words: four tiles as one 16-byte store per lane, fewer tile by tile.
 __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t nst, uint32_t *base, uint32_t stflags) {
     const int lane = rd_lane_now();
     if (nst == RD_MF_STAGE_TILES) {
@@ -525,27 +347,7 @@ __device__ __forceinline__ void rd_mf_store_staged(uint32_t stage_addr, uint32_t
         for (int j = 0; j < RD_MF_STAGE_TILES / 4; j++) {
             const rd_u4v v = rd_lds_read16u(stage_addr + 16 * (lane + 64 * j));
             // non-temporal: the words are read next by another kernel, never again by this one (0.3-1.3 % faster;
-            // RD_K1_STFLAGS & 1 switches to plain stores for A/B runs)
-#ifdef RD_DIAG
-            // RD_K1_STFLAGS & 512 (diagnostic library, WRONG results): three stores in four are skipped - what the whole
-            // kernel would gain if most tiles' words never had to leave the chip (profiles/r03_store_skip.txt)
-            if ((stflags & 512) && (((size_t)base >> 10) & 3) != 0) continue;
-            if ((stflags & 1024)) continue;  // ... and none at all
-            // RD_K1_STFLAGS bits 3-5 (diagnostic library): the store's cache policy bits spelled out - which of them,
-            // if any, changes what the word stores cost beside the tile loads (profiles/r03_store_policy.txt)
-            if ((stflags >> 3) & 7) {
-                rd_u4v *ptr = (rd_u4v *)(base + 4 * (lane + 64 * j));
-                switch ((stflags >> 3) & 7) {
-                    case 1: asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(ptr), "v"(v) : "memory"); break;
-                    case 2: asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(v) : "memory"); break;
-                    case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory"); break;
-                    case 4: asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(ptr), "v"(v) : "memory"); break;
-                    case 5: asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(ptr), "v"(v) : "memory"); break;
-                    default: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(ptr), "v"(v) : "memory"); break;
-                }
-                continue;
-            }
-#endif
+            // RD_K1_STFLAGS & 1 of the diagnostic library switches to plain stores for A/B runs)
             if (!(stflags & 1)) __builtin_nontemporal_store(v, (rd_u4v *)(base + 4 * (lane + 64 * j)));
             else *(rd_u4v *)(base + 4 * (lane + 64 * j)) = v;
         }
@@ -613,109 +415,6 @@ __device__ __forceinline__ void rd_mf_read_window(uint32_t a_prv, uint32_t a_own
                  : "memory");
 }
 
-// RD_OPT_FPROBE (diagnostic library only): the work of an in-tile preamble search, to MEASURE what fusing k_search
-// into this kernel would cost before building the list-driven remainder it would need.  Per tile:
-// the lane's finished word goes to a 72-word ring in LDS (8 words of history + the tile's 64), the lane reads the 8
-// words that end with its own and evaluates the 16 taps of py:171-188 for the 32 positions of the word seven back
-// (15 funnel shifts + the and / or tree, as k_search does for each of its four words), a wave-uniform branch takes the
-// rare match.  The matches go nowhere (the words are not yet fixed up and the tile's first seven words see the
-// previous tile of the WAVE, not of the stream): the timing is the result.
-template <int S_, int P_, uint64_t PRE_>
-__device__ __forceinline__ uint32_t rd_mf_search_probe(uint32_t ring_addr, uint32_t wi, uint32_t word) {
-    rd_lds_write4(ring_addr + 4 * (8 + wi), word);
-    uint32_t r[8];
-    asm volatile("ds_read2_b32 %0, %4 offset0:1 offset1:2\n\tds_read2_b32 %1, %4 offset0:3 offset1:4\n\t"
-                 "ds_read2_b32 %2, %4 offset0:5 offset1:6\n\tds_read2_b32 %3, %4 offset0:7 offset1:8\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(*(rd_u2v *)&r[0]), "=&v"(*(rd_u2v *)&r[2]), "=&v"(*(rd_u2v *)&r[4]), "=&v"(*(rd_u2v *)&r[6])
-                 : "v"(ring_addr + 4 * wi) : "memory");
-    uint32_t m = 0xFFFFFFFFu, any = 0;
-#pragma unroll
-    for (int k = 0; k < P_; k++) {
-        const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
-        const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[wj + 1 < 8 ? wj + 1 : 7], r[wj], sh) : r[wj];
-        if ((PRE_ >> k) & 1) m &= v; else any |= v;
-    }
-    m &= ~any;
-    if (wi >= 56) rd_lds_write4(ring_addr + 4 * (wi - 56), word);  // the next tile's history
-    return m;
-}
-
-// RD_OPT_FSEARCH (RD_DEMOD_FUSED_SEARCH): the preamble test of py:171-188 inside this kernel, for the Davis
-// configuration.  A wave keeps a ring of 72 (word, flagged) pairs in LDS: eight entries of history (the last eight
-// words of its previous tile) and the tile's 64.  Lane wi evaluates the 32 positions of word wi - 7 of the tile
-// (window = that word and the seven behind it, the last one its own): 15 funnel shifts and the and / or tree, as
-// k_search does per output word.  What it reports: positions p <= p_hi whose window holds no FLAGGED word (a word with a
-// group on the fix-up list: its bits may still change) and lies in words this wave has seen - at a chunk's first tile
-// the ring's history is another stream's or another chunk's, and lanes 0-6 report nothing.  The positions left out are
-// exactly those k_search_rem (rd_kernels.hip) evaluates after k_fixup: the windows around every listed word and the
-// seven words in front of every chunk start.
-template <int S_, int P_, uint64_t PRE_>
-__device__ __forceinline__ uint32_t rd_mf_search_tile(uint32_t ring_addr, uint32_t wi, uint32_t word, uint32_t flagged) {
-    asm volatile("ds_write_b64 %0, %1" : : "v"(ring_addr + 8 * (8 + wi)), "v"(rd_u2v{word, flagged}) : "memory");
-    uint32_t r[8];
-    asm volatile("ds_read2_b32 %0, %4 offset0:2 offset1:4\n\tds_read2_b32 %1, %4 offset0:6 offset1:8\n\t"
-                 "ds_read2_b32 %2, %4 offset0:10 offset1:12\n\tds_read2_b32 %3, %4 offset0:14 offset1:16\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(*(rd_u2v *)&r[0]), "=&v"(*(rd_u2v *)&r[2]), "=&v"(*(rd_u2v *)&r[4]), "=&v"(*(rd_u2v *)&r[6])
-                 : "v"(ring_addr + 8 * wi) : "memory");
-    uint32_t m = 0xFFFFFFFFu, any = 0;
-#pragma unroll
-    for (int k = 0; k < P_; k++) {
-        const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
-        const uint32_t v = sh ? __builtin_amdgcn_alignbit(r[wj + 1 < 8 ? wj + 1 : 7], r[wj], sh) : r[wj];
-        if ((PRE_ >> k) & 1) m &= v; else any |= v;
-    }
-    return m & ~any;
-}
-// the rare part (some lane has a match in one tile of ~30 on noise), all lanes: bit b of m = position
-// 32 (word0 + wi - 7) + b of stream s.  A match goes to the WAVE's own list in global memory - plain stores, the
-// count in a scalar register: a returning atomic per match (on the stream's bucket counter) cost this kernel 8 % -
-// and k_search_rem moves the lists' entries into the per-stream buckets.
-template <int S_, int P_>
-__device__ __forceinline__ void rd_mf_emit_matches(uint32_t ring_addr, uint32_t wi, uint32_t m, uint32_t s, uint32_t word0,
-                                                   const rd_mf_extra *ex, uint32_t wave_id, uint32_t &nmatch) {
-    const int p_hi = ex->p_hi;
-    uint32_t keep = 0;
-    if (m) {
-        // the flags of the window's eight words (odd dwords of the ring's pairs): one wait
-        uint32_t f[8];
-        asm volatile("ds_read2_b32 %0, %4 offset0:3 offset1:5\n\tds_read2_b32 %1, %4 offset0:7 offset1:9\n\t"
-                     "ds_read2_b32 %2, %4 offset0:11 offset1:13\n\tds_read2_b32 %3, %4 offset0:15 offset1:17\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(*(rd_u2v *)&f[0]), "=&v"(*(rd_u2v *)&f[2]), "=&v"(*(rd_u2v *)&f[4]), "=&v"(*(rd_u2v *)&f[6])
-                     : "v"(ring_addr + 8 * wi) : "memory");
-        const uint32_t fo6 = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6], fo7 = fo6 | f[7];
-        static_assert(((P_ - 1) * S_) >> 5 == 6 && ((P_ - 1) * S_ + 31) >> 5 == 7, "a window ends in its seventh or eighth word");
-        uint32_t mm = m;
-        while (mm) {
-            const uint32_t b = (uint32_t)__builtin_ctz(mm);
-            mm &= mm - 1;
-            const int p = 32 * (int)(word0 + wi - 7) + (int)b;
-            const bool last7 = ((b + (uint32_t)((P_ - 1) * S_)) >> 5) == 7;
-            // (a flagged word in the window: k_search_rem reports the position, from the bits k_fixup leaves)
-            if (p <= p_hi && !(last7 ? fo7 : fo6)) keep |= 1u << b;
-        }
-    }
-    const uint32_t c = (uint32_t)__popc(keep);
-    uint32_t incl = c;
-#pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
-        if (rd_lane_now() >= sh) incl += up;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-    uint32_t at = nmatch + incl - c;
-    int2 *mine = ex->wmatch + (size_t)wave_id * RD_WAVE_MATCHES;
-    while (keep) {
-        const uint32_t b = (uint32_t)__builtin_ctz(keep);
-        keep &= keep - 1;
-        if (at < RD_WAVE_MATCHES) mine[at] = int2{(int)s, 32 * (int)(word0 + wi - 7) + (int)b};
-        at++;
-    }
-    nmatch += __builtin_amdgcn_readfirstlane(total);
-}
-
 // In-kernel stamps (RD_OPT_STAMP, diagnostic library only; cdna_hip_programming.md section 7): one statement with
 // its own lgkmcnt(0), fenced against the scheduler on both sides.
 __device__ __forceinline__ uint64_t rd_stamp() {
@@ -733,115 +432,78 @@ __device__ __forceinline__ uint64_t rd_stamp_real() {  // 100 MHz constant clock
     return t;
 }
 
+
 // DBG: 0 product; 3 also dumps g (dbg_g[tile][2048][2], sample order; the test hook).  Diagnostic library only
-// (-DRD_DIAG, librtldavis_hip_diag.so; garbage results): 1 no global loads; 2 loads + LDS reads + stores only;
-// 4 = 1 without the MFMAs; 5 = 1 with the MFMAs and almost no vector work; 6 loads only; 7 no guard band;
-// 9 = 16 of the 24 MFMAs per tile; 10 = 4 with the loads; 11 = 5 with the loads.
-// OPT (compile time): RD_OPT_PIPE block B+1's MFMAs before block B's vector work; RD_OPT_HALO the 16 bytes in front
-// of a tile come from the previous tile's registers inside a chunk (four LDS-DMA instructions per tile, not five);
-// RD_OPT_STAMP (diagnostic library) s_memtime stamps, per-wave sums in dbg_g.
-#define RD_OPT_PIPE 1
-#define RD_OPT_HALO 2
-#define RD_OPT_STAMP 4
-#define RD_OPT_B8 8   // the 8-output formulation: 16 MFMAs per tile (rd_mf8_tile)
-// stflags bits 16-23 (self-fix variant, test hook): entries a wave keeps before the global list (0 = RD_MF_PEND_SELF)
-#define RD_OPT_SELF 32    // self-fix variant (rd_mf_selffix): launched for RD_DEMOD_SELF_FIX, a kernel of its own so that
-                          // the default kernel carries neither the call nor its scratch
-#define RD_OPT_FSEARCH 64 // fused-search variant (rd_mf_search_tile), launched for RD_DEMOD_FUSED_SEARCH
-#define RD_OPT_FPROBE 16  // diagnostic library: what an in-tile preamble test would cost (rd_mf_search_probe)
+// (-DRD_DIAG, librtldavis_hip_diag.so; garbage results): 1 no global loads; 2 loads + LDS reads + stores only; 6 loads
+// only; 7 no guard band.  STAMP (diagnostic library): s_memtime stamps, per-wave sums in dbg_g.
+// stflags: 1 plain instead of non-temporal word stores, 2 all stores into one MiB (wrong results), 4 no s_setprio,
+// 4096 equal shares of chunks per wave instead of the work queues (1 - 4096: diagnostic library, RD_K1_STFLAGS);
+// RD_STF_BUCKETS: the fix-up entries go to per-group buckets (RD_DEMOD_FIX_BUCKETS, set by the host).
 #define RD_STAMP_WORDS 12
-#define RD_STF_BUCKETS 8192u  // stflags: fix-up entries into per-group buckets (RD_DEMOD_FIX_BUCKETS)
-template <int DBG, int NBUF, int OPT>
+#define RD_STF_BUCKETS 8192u
+template <int DBG, bool STAMP>
 __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layout lay, uint32_t tiles_per_stream, uint32_t total_tiles,
                                                          uint32_t chunk, uint32_t *fix_list, uint32_t fix_cap,
                                                          uint32_t *counters, float *dbg_g, uint32_t stflags) {
-    // NBUF = 1 (default): one image buffer, tile i+1 in flight while tile i is computed, 4 workgroups per CU.
-    // NBUF = 2 (RD_K1_NBUF=2): two buffers, tiles i+1 and i+2 in flight, 3 workgroups per CU - measured slower
-    // (0.54 vs 0.53 ms: the fourth wave per SIMD is worth more than the second tile in flight).
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[RD_MF_WAVES][NBUF][RD_MF_IMG_PAD];
+    // one image buffer per wave: tile i+1 in flight while tile i is computed, 4 workgroups per CU
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[RD_MF_WAVES][RD_MF_IMG_PAD];
     __shared__ __attribute__((aligned(32))) uint8_t s_xb[RD_MF_WAVES][RD_MF_XB_BYTES];
-    constexpr uint32_t PEND = (OPT & RD_OPT_SELF) ? RD_MF_PEND_SELF : RD_MF_PEND;
-    __shared__ uint32_t s_pend[RD_MF_WAVES][PEND];
+    __shared__ uint32_t s_pend[RD_MF_WAVES][RD_MF_PEND];
     // packed words of up to four consecutive tiles of a stream, stored together: one 16-byte store per lane
     // (1 KiB contiguous per wave) instead of four dword stores (round 1: a dword store per tile cost 20 % of
     // the read bandwidth, profiles/r01_ubench_read_bw.txt)
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[RD_MF_WAVES][RD_MF_STAGE_TILES][64];
-    constexpr bool LOADS = DBG != 1 && DBG != 4 && DBG != 5;
+    constexpr bool LOADS = DBG != 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint8_t *img0 = s_img[wave][0];
+    uint8_t *img0 = s_img[wave];
     uint8_t *xb = s_xb[wave];
     uint32_t *mypend = s_pend[wave];
     uint32_t npend = 0;
     // RD_STF_BUCKETS: the fix-up entries go to per-group buckets whose counters the last pointer argument names
-    constexpr bool CAN_BUCKET = DBG == 0 && !(OPT & (RD_OPT_FSEARCH | RD_OPT_STAMP | RD_OPT_SELF));
+    constexpr bool CAN_BUCKET = DBG == 0 && !STAMP;
     uint32_t *bucket_cnt = (CAN_BUCKET && (stflags & RD_STF_BUCKETS)) ? (uint32_t *)dbg_g : nullptr;
-    uint32_t fs_nmatch = 0;  // fused search: entries in this wave's own match list (wave-uniform)
 
     const int n = lane & 31, h = lane >> 5;
-    // tap fragments: 6 x 4 registers for the whole kernel
-    constexpr bool B8 = (OPT & RD_OPT_B8) != 0;
-    rd_h8 Ahi[3], Alo[3];
-    if (!B8) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            Ahi[d] = *(const rd_h8 *)g_mf_taps.v[0][d][lane];
-            Alo[d] = *(const rd_h8 *)g_mf_taps.v[1][d][lane];
-        }
-        // a use in front of the loop: the wait for these six loads must not end up inside it, where it would
-        // be a vmcnt(0) that also drains the prefetched tiles in every iteration
-        asm volatile("" : "+v"(Ahi[0]), "+v"(Ahi[1]), "+v"(Ahi[2]), "+v"(Alo[0]), "+v"(Alo[1]), "+v"(Alo[2]));
-    }
+    // tap fragments (two, 8 registers) and the C operand of a block's first MFMA (-D_hi in the hi-digit rows, 0 in the
+    // lo-digit rows: 16 registers) for the whole kernel
     rd_h8 A8[2];
-    rd_f16v dcC;  // the C operand of a block's first MFMA: -D_hi in the hi-digit rows, 0 in the lo-digit rows
-    if (B8) {
-        A8[0] = *(const rd_h8 *)g_mf_taps8.v[0][lane];
-        A8[1] = *(const rd_h8 *)g_mf_taps8.v[1][lane];
-        const float dchi = -(float)RD_MF_DHI / 16777216.0f;
+    rd_f16v dcC;
+    A8[0] = *(const rd_h8 *)g_mf_taps8.v[0][lane];
+    A8[1] = *(const rd_h8 *)g_mf_taps8.v[1][lane];
+    const float dchi = -(float)RD_MF_DHI / 16777216.0f;
 #pragma unroll
-        for (int i = 0; i < 16; i++) dcC[i] = i < 8 ? dchi : 0.0f;
-        // opaque: sixteen registers for the whole kernel, not sixteen v_mov in front of every block
-        asm volatile("" : "+v"(A8[0]), "+v"(A8[1]), "+v"(dcC));
-    }
-    // window addresses in the image (buffer 0; buffer 1 is RD_MF_IMG_PAD further)
+    for (int i = 0; i < 16; i++) dcC[i] = i < 8 ? dchi : 0.0f;
+    // opaque: sixteen registers for the whole kernel, not sixteen v_mov in front of every block - and a use in front
+    // of the loop: the wait for the tap loads must not end up inside it, where it would be a vmcnt(0) that also drains
+    // the prefetched tile in every iteration
+    asm volatile("" : "+v"(A8[0]), "+v"(A8[1]), "+v"(dcC));
+    // window addresses in the image
     const uint32_t img_addr = rd_lds_addr(img0);
     const uint32_t own = 16 + RD_MF_GROUP_BYTES * (n >> 3) + 16 * (n & 7) + 8 * h;
     const uint32_t prv = n == 0 ? 8 * h
                        : (n & 7) ? own + 16 * 55
                                  : 16 + RD_MF_GROUP_BYTES * ((n >> 3) - 1) + 16 * 63 + 8 * h;
-    // Predecessor exchange.  Step b writes (g6, g7) of block b; the lane that follows in time is
-    // (n, 1, b) after (n, 0, b), (n, 0, b) after (n, 1, b-1), (n, 0, 0) after (n-1, 1, 3), and (0, 0, 0) after
-    // lane 63 of the previous tile.  Buffers: X0 at 0, X1 and X3 at 1024, X2 at 2048 (X1 is dead when X3 is
-    // written), two carry slots at 3072 (lane 63's X3, alternating with the tile parity).
+    // Predecessor exchange (rd_mf8_addr): Q (block 0) at 0, P1 (odd blocks) at 1024, P0 (even blocks >= 2) at 2048, two
+    // carry slots at 3072 (lane 63's block 7, alternating with the tile parity).
     const uint32_t xb_addr = rd_lds_addr(xb), pend_addr = rd_lds_addr(mypend);
-    const uint32_t pend_limit = (OPT & RD_OPT_SELF) && ((stflags >> 16) & 0xFFu) && ((stflags >> 16) & 0xFFu) < PEND ? ((stflags >> 16) & 0xFFu) : PEND;
     const uint32_t stage_addr = rd_lds_addr(s_stage[wave]);
-    const uint32_t xw = xb_addr + 16 * lane;                       // + 0 / 1024 / 2048 for b = 0 / 1 / 2
-    uint32_t xw3 = xb_addr + (lane == 63 ? 3072 : 1024 + 16 * lane);
-    const uint32_t xr1 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 16 * (lane + 32));          // X1[l-32] | X0[l+32]
-    const uint32_t xr2 = xb_addr + (h ? 2048 + 16 * (lane - 32) : 1024 + 16 * (lane + 32));   // X2[l-32] | X1[l+32]
-    const uint32_t xr3 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 2048 + 16 * (lane + 32));   // X3[l-32] | X2[l+32]
-    uint32_t xr0 = xb_addr + (h ? 16 * (lane - 32) : lane ? 1024 + 16 * (lane + 31) : 3072 + 16);  // X0[l-32] | X3[l+31]
     const uint32_t rtoggle = lane == 0 ? 16u : 0u, wtoggle = lane == 63 ? 16u : 0u;
     rd_mf8_addr ad8;
-    ad8.xw = xw;
+    ad8.xw = xb_addr + 16 * lane;
     ad8.xw7 = xb_addr + (lane == 63 ? 3072 : 1024 + 16 * lane);
     ad8.rd1 = xb_addr + (h ? 1024 + 16 * (lane - 32) : 16 * (lane + 32));
     ad8.rdE = xb_addr + (h ? 2048 + 16 * (lane - 32) : 1024 + 16 * (lane + 32));
     ad8.rdO = xb_addr + (h ? 1024 + 16 * (lane - 32) : 2048 + 16 * (lane + 32));
     ad8.rd0 = xb_addr + (h ? 16 * (lane - 32) : lane ? 1024 + 16 * (lane + 31) : 3072 + 16);
     if (lane < 8) ((uint32_t *)(xb + 3072))[lane] = 0;  // carry slots: finite values from the start
-    // -D_hi * 2^-24 (the -127.4 offset): read into all sixteen positions of the hi accumulator in front of
-    // every block's MFMAs - from LDS rather than from a 16-register tuple held for the whole kernel
-    if (lane < 4) ((float *)(xb + 3104))[lane] = -(float)RD_MF_DHI / 16777216.0f;
-    const uint32_t psel = h ? 0x07030602u : 0x05010400u;
 
     const uint32_t nwaves = gridDim.x * RD_MF_WAVES;
     const uint32_t wave_id = blockIdx.x * RD_MF_WAVES + wave;
     // RD_K1_STFLAGS & 4096: every wave takes chunks wave_id, wave_id + nwaves, ... (equal shares: A/B); the queue
     // needs chunks of at least four tiles (the id of the following chunk is asked for in a chunk's first
     // iteration, read in its second and first used in its last but one)
-    const bool dynamic = !(stflags & 4096) && chunk >= 4 && NBUF == 1;
+    const bool dynamic = !(stflags & 4096) && chunk >= 4;
     uint32_t cur_chunk = wave_id;      // the chunk `cur` is in
     rd_mf_nextchunk nextc = {0xFFFFFFFFu, 0, 0};
     if (!dynamic) nextc = rd_mf_chunk_at((uint64_t)cur_chunk + nwaves, chunk, tiles_per_stream, total_tiles);
@@ -855,12 +517,10 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     cur.ti = cur.tile % tiles_per_stream;
     cur.inchunk = 0;
     rd_mf_pos nx1 = rd_mf_next(cur, chunk, tiles_per_stream, nextc);
-    uint32_t buf = 0;  // image buffer of the current tile (wave-uniform)
 
     uint32_t nst = 0;             // tiles staged (wave-uniform)
     uint32_t *st_base = nullptr;  // word 0 of the first staged tile
     bool st_flush = false;        // the staged group ends here (next tile is not the next 64 words)
-    constexpr bool STAMP = (OPT & RD_OPT_STAMP) != 0;
     // stamp sums (wave-uniform, scalar registers): cycles at the loop-top wait, from there to the last load issued,
     // and in the arithmetic; the waits that follow an iteration with a word store apart
     uint64_t sm_wait = 0, sm_gap = 0, sm_comp = 0, sm_wait_st = 0, sm_t0 = 0, sm_r0 = 0, sm_mark = 0, sm_wmax = 0;
@@ -868,16 +528,14 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     bool sm_stored = false;
     if (STAMP) { sm_t0 = rd_stamp(); sm_r0 = rd_stamp_real(); }
     if (LOADS && cur.tile < total_tiles) rd_mf_issue(lay, cur.s, cur.ti, img0, lane);
-    if (NBUF == 2 && LOADS && nx1.tile < total_tiles) rd_mf_issue(lay, nx1.s, nx1.ti, img0 + RD_MF_IMG_PAD, lane);
     if (STAMP) sm_mark = rd_stamp();
     while (cur.tile < total_tiles) {
         const uint32_t tile = cur.tile, s = cur.s, ti = cur.ti, inchunk = cur.inchunk;
         uint64_t sm_a = 0;
         if (STAMP) { sm_a = rd_stamp(); sm_comp += sm_a - sm_mark; }
-        // this tile has landed when at most the next tile's five loads are outstanding (vmcnt counts in
-        // issue order; the previous iteration's word store and list flush are older or harmless)
-        if (NBUF == 2 && nx1.tile < total_tiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(grab) : : "memory");
+        // this tile has landed (vmcnt counts in issue order; the previous iteration's word store and list flush are
+        // older or harmless)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(grab) : : "memory");
         uint64_t sm_b = 0;
         if (STAMP) {
             sm_b = rd_stamp();
@@ -910,9 +568,8 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         // tile arrived should not queue behind three other waves' vector work before it can ask for the next
         if (!(stflags & 4)) __builtin_amdgcn_s_setprio(3);  // (RD_K1_STFLAGS & 4 switches it off: A/B)
         rd_u2v D[9];
-        const uint32_t boff = buf * RD_MF_IMG_PAD;
-        rd_mf_read_window(img_addr + boff + prv, img_addr + boff + own, D);
-        // the window is in registers: this buffer takes the tile after next
+        rd_mf_read_window(img_addr + prv, img_addr + own, D);
+        // the window is in registers: the image takes the next tile
         // stores of finished tiles go out here, before the loads (they share vmcnt, in issue order)
         if (nst == RD_MF_STAGE_TILES || (nst && st_flush)) {
             rd_mf_store_staged(stage_addr, nst, st_base, stflags);
@@ -920,157 +577,43 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
             if (STAMP) sm_stored = true;
         }
         const rd_mf_pos nx2 = rd_mf_next(nx1, chunk, tiles_per_stream, nextc);
-        const rd_mf_pos fetch = NBUF == 2 ? nx2 : nx1;
-        // RD_OPT_HALO: when the tile fetched next is the one that follows this tile in its stream, the 16 bytes in
+        // Halo carry: when the tile fetched next is the one that follows this tile in its stream, the 16 bytes in
         // front of it are this tile's last 16 - k-step 8 of column 31, in the registers of lanes 31 and 63 - and go
         // into the image's halo slot by one ds_write_b64 instead of a fifth LDS-DMA instruction (a 16-byte request of
         // its own through the whole memory pipe).  The window read above has completed (its lgkmcnt(0)), the next
         // window read follows in LDS order; the four group loads do not touch the slot.
         bool halo_dma = true;
-        if ((OPT & RD_OPT_HALO) && NBUF == 1) {
-            const bool follows = fetch.tile < total_tiles && fetch.s == s && fetch.ti == ti + 1;  // wave-uniform
+        {
+            const bool follows = nx1.tile < total_tiles && nx1.s == s && nx1.ti == ti + 1;  // wave-uniform
             if (follows) {
                 halo_dma = false;
                 if (n == 31) asm volatile("ds_write_b64 %0, %1" : : "v"(img_addr + 8 * h), "v"(D[8]) : "memory");
             }
         }
-        if (LOADS && fetch.tile < total_tiles) rd_mf_issue(lay, fetch.s, fetch.ti, img0 + boff, lane, halo_dma);
+        if (LOADS && nx1.tile < total_tiles) rd_mf_issue(lay, nx1.s, nx1.ti, img0, lane, halo_dma);
         if (!(stflags & 4)) __builtin_amdgcn_s_setprio(0);
-#ifdef RD_DIAG
-        // RD_K1_STFLAGS bits 24-27 = mode, bits 28-31 = n (diagnostic library): pacing experiments - s_sleep n behind the
-        // tile's loads for a SUBSET of the waves, so that the waves of a CU stop running through the tile in step
-        // (profiles/r03_pacing.txt).  1: odd waves (= SIMDs 1 and 3), 2: odd workgroups, 3: (wave ^ workgroup) odd,
-        // 5: wave w sleeps w n, 6: every wave (control), 7: waves 2 and 3, 8: wave 3 only
-        {
-            const uint32_t pm = (stflags >> 24) & 15u, pn = (stflags >> 28) & 15u;
-            bool sl = false;
-            if (pm == 1) sl = (wave & 1) != 0;
-            else if (pm == 2) sl = (blockIdx.x & 1) != 0;
-            else if (pm == 3) sl = ((wave ^ blockIdx.x) & 1) != 0;
-            else if (pm == 6) sl = true;
-            else if (pm == 7) sl = (wave & 2) != 0;
-            else if (pm == 8) sl = wave == 3;
-            if (sl) {
-                if (pn <= 1) __builtin_amdgcn_s_sleep(1);
-                else if (pn == 2) __builtin_amdgcn_s_sleep(2);
-                else if (pn <= 4) __builtin_amdgcn_s_sleep(4);
-                else __builtin_amdgcn_s_sleep(8);
-            }
-            if (pm == 5) {
-                if (wave == 1) __builtin_amdgcn_s_sleep(1);
-                else if (wave == 2) __builtin_amdgcn_s_sleep(2);
-                else if (wave == 3) __builtin_amdgcn_s_sleep(3);
-            }
-        }
-#endif
         if (STAMP) { sm_mark = rd_stamp(); sm_gap += sm_mark - sm_b; }
 
-        uint32_t word = 0, fbytes = 0;
+        uint32_t word = 0;
         bool slow_taken = false;
-        uint32_t fbw8 = 0;  // B8: the word's flag bytes, already gathered
+        uint32_t fbw8 = 0;  // the word's flag bytes, already gathered
         if (DBG == 2 || DBG == 6) {
 #pragma unroll
             for (int j = 0; j < 9; j++) word ^= D[j].x ^ D[j].y;
-        } else if (B8) {
+        } else {
             float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 4 * h + 1) * 2 : nullptr;
             const int dleft = RD_TILE_SAMPLES - (64 * n + 4 * h + 1);
             rd_mf8_tile<DBG>(A8, dcC, D, ad8, word, fbw8, slow_taken, dg, dleft);
             ad8.rd0 ^= rtoggle;
             ad8.xw7 ^= wtoggle;
-        } else {
-            rd_h8 bf[3];
-            rd_mf_state stt;
-            stt.W = 0; stt.w0 = 0; stt.fbytes = 0; stt.slow = false; stt.g0r = 0.0f; stt.g0i = 0.0f;
-            float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 8 * h + 1) * 2 : nullptr;
-            const int dleft = RD_TILE_SAMPLES - (64 * n + 8 * h + 1);  // outputs of this lane inside the tile
-            if ((OPT & RD_OPT_PIPE) && DBG != 5 && DBG != 11) {
-                // block B+1's burst is issued before block B's tail: the tail's vector work has no use for the
-                // matrix pipe's results and runs under the MFMAs (the scheduler is free to interleave them; the
-                // fences only keep a burst behind the combine that frees its accumulator registers)
-                rd_f16v ah, al;
-                float g[16];
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_burst<0, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_combine(ah, al, g);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_burst<1, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
-                rd_mf_tail<0, DBG, 0>(g, xw, 0, stt, dg, dleft);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_combine(ah, al, g);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_burst<2, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
-                rd_mf_tail<1, DBG, 1024>(g, xw, xr1, stt, dg, dleft);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_combine(ah, al, g);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_burst<3, DBG>(Ahi, Alo, D, bf, xb_addr + 3104, ah, al);
-                rd_mf_tail<2, DBG, 2048>(g, xw, xr2, stt, dg, dleft);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_mf_combine(ah, al, g);
-                rd_mf_tail<3, DBG, 0>(g, xw3, xr3, stt, dg, dleft);
-            } else {
-                rd_mf_block<0, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw, 0, stt, dg, dleft);
-                rd_mf_block<1, DBG, 1024>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr1, stt, dg, dleft);
-                rd_mf_block<2, DBG, 2048>(Ahi, Alo, D, bf, xb_addr + 3104, xw, xr2, stt, dg, dleft);
-                rd_mf_block<3, DBG, 0>(Ahi, Alo, D, bf, xb_addr + 3104, xw3, xr3, stt, dg, dleft);
-            }
-            {   // block 0's first two numerators: W holds 30 bits, its bits 31, 30 are theirs
-                rd_f4v p = rd_lds_read16<0>(xr0);
-                rd_lds_wait(p);
-                float t0, t1;
-                const float n0 = rd_mf_num(p.x, p.y, p.z, p.w, t0);
-                const float n1 = rd_mf_num(p.z, p.w, stt.g0r, stt.g0i, t1);
-                // byte 0 of the word: (n0, n1, block 0's six), on top of the 24 bits of blocks 1-3
-                uint32_t b0 = rd_shift_in_sign(0u, n0);
-                b0 = rd_shift_in_sign(b0, n1);
-                b0 = (b0 << 6) | stt.w0;
-                stt.W = (b0 << 24) | stt.W;
-                if (DBG == 0 || DBG == 3) {
-                    const float nm = rd_mf_guard(rd_min3abs(3.0e38f, n0, n1), rd_max3abs(0.0f, t0, t1));
-                    if (rd_mf_any(!(nm > RD_MF_C0_MAX))) {
-                        stt.slow = true;
-                        float F = rd_max3abs(0.0f, p.x, p.y);
-                        F = rd_max3abs(F, p.z, p.w);
-                        F = rd_max3abs(F, stt.g0r, stt.g0i);
-                        if (!(nm > rd_mf_c0(F))) stt.fbytes |= 1u;
-                    }
-                }
-            }
-            xr0 ^= rtoggle;
-            xw3 ^= wtoggle;
-            word = __builtin_bitreverse32(stt.W);  // byte b = the signs of block b's group
-            fbytes = stt.fbytes;
-            slow_taken = stt.slow;
         }
-        // The lane holds bytes (groups) 2b + h of its column's two words: gather word h of the column
-        // (lanes n and n + 32 exchange halves), the flags likewise.
         uint32_t gmask = 0;
-        if (!B8 || DBG == 2 || DBG == 6) {
-            const auto w2 = __builtin_amdgcn_permlane32_swap(word, word, false, false);  // [0]: half 0's, [1]: half 1's
-            word = __builtin_amdgcn_perm(w2[1], w2[0], psel);
-        }
-#ifdef RD_DIAG
-        if constexpr ((OPT & RD_OPT_FPROBE) != 0) {
-            __shared__ uint32_t s_ring[RD_MF_WAVES][72];
-            const uint32_t m = rd_mf_search_probe<14, 16, 0x91D3ull>(rd_lds_addr(s_ring[wave]), (uint32_t)(2 * n + h), word);
-            if (rd_mf_any(m != 0)) {  // rare (2^-16 per position on noise): where the match would be appended
-                if (m) rd_lds_write4(rd_lds_addr(s_ring[wave]) + 4 * 70, m);
-            }
-        }
-#endif
         const bool carry = inchunk > 0 && ti > 0;  // previous iteration = previous tile of this stream
         const uint32_t run = ti * 64 + 2 * n + h;  // word index in the stream
         const uint32_t t0 = run * RD_RUN;
-        // (fbytes is only ever set inside the wave-uniform second-level branches: no ballot in the common case)
-        const bool any_flag = slow_taken && rd_mf_any(B8 ? fbw8 != 0 : fbytes != 0);
-        if (B8) {
-            if (any_flag) gmask = ((fbw8 * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
-        } else if (any_flag) {  // wave-uniform, rare
-            const auto f2 = __builtin_amdgcn_permlane32_swap(fbytes, fbytes, false, false);
-            const uint32_t fb = __builtin_amdgcn_perm(f2[1], f2[0], psel);
-            gmask = ((fb * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
-        }
+        // (the flag bytes are only ever set inside the wave-uniform second-level branches: no ballot in the common case)
+        const bool any_flag = slow_taken && rd_mf_any(fbw8 != 0);
+        if (any_flag) gmask = ((fbw8 * 0x00204081u) >> 21) & 0xFu;  // bytes 0/1 -> bits
         if (!carry && lane == 0) {  // (the scalar test first: one tile in sixteen)
             if (ti == 0 && !lay.hist_mode) gmask = 0xFu;  // zero history: first run exact
             else gmask |= 1u;                             // no predecessors for the tile's first group
@@ -1101,22 +644,11 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         } else {
             gmask = 0;
         }
-        if (DBG == 1 || DBG == 2 || (DBG >= 4 && DBG != 7)) gmask = 0;  // (incl. 6, 9)
-        if constexpr ((OPT & RD_OPT_FSEARCH) != 0) {
-            __shared__ __attribute__((aligned(8))) uint32_t s_ring[RD_MF_WAVES][2 * 72];
-            const uint32_t ring_addr = rd_lds_addr(s_ring[wave]);
-            const uint32_t wi = (uint32_t)(2 * n + h);
-            const uint32_t flagged = gmask != 0 ? 1u : 0u;
-            uint32_t m = rd_mf_search_tile<14, 16, 0x91D3ull>(ring_addr, wi, word, flagged);
-            if (!carry && wi < 7) m = 0;  // no history of this stream in the ring: k_search_rem's boundary pass
-            if (rd_mf_any(m != 0)) rd_mf_emit_matches<14, 16>(ring_addr, wi, m, s, ti * 64, (const rd_mf_extra *)dbg_g, wave_id, fs_nmatch);
-            // the next tile's history (after the flags above have been read: LDS operations of a wave run in order)
-            if (wi >= 56) asm volatile("ds_write_b64 %0, %1" : : "v"(ring_addr + 8 * (wi - 56)), "v"(rd_u2v{word, flagged}) : "memory");
-        }
+        if (DBG == 1 || DBG == 2 || DBG == 6) gmask = 0;
         const uint64_t fm = (any_flag || !carry) ? __ballot(gmask != 0) : 0;
         if (fm) {
             const uint32_t nf = (uint32_t)__popcll(fm);
-            if (npend + nf > pend_limit) {  // (with self-fix: the rare overflow goes to the global list, k_fixup then runs)
+            if (npend + nf > RD_MF_PEND) {
                 rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, (uint32_t)lay.bits_stride, bucket_cnt);
                 npend = 0;
             }
@@ -1128,25 +660,9 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         }
         cur = nx1;
         nx1 = nx2;
-        if (NBUF == 2) buf ^= 1;
     }
     if (nst) rd_mf_store_staged(stage_addr, nst, st_base, stflags);
-    if (npend) {
-        if constexpr ((OPT & RD_OPT_SELF) != 0)
-            rd_mf_selffix(pend_addr, npend, lay, counters + RD_CNT_QUEUE0 + (wave_id % RD_NQUEUE) * RD_QUEUE_STRIDE + RD_SELF_WORD);
-        else
-            rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, (uint32_t)lay.bits_stride, bucket_cnt);
-    }
-    if constexpr ((OPT & RD_OPT_FSEARCH) != 0) {
-        if (rd_lane_now() == 0) {
-            const rd_mf_extra *ex = (const rd_mf_extra *)dbg_g;
-            ex->wcount[wave_id] = fs_nmatch < RD_WAVE_MATCHES ? fs_nmatch : RD_WAVE_MATCHES;
-            if (fs_nmatch > RD_WAVE_MATCHES) {  // the host searches in full; the count is left for its debug line
-                atomicOr(&counters[RD_CNT_OVF], 4u);
-                counters[RD_CNT_SLOTS - 1] = fs_nmatch;
-            }
-        }
-    }
+    if (npend) rd_mf_flush(mypend, npend, fix_list, fix_cap, counters, (uint32_t)lay.bits_stride, bucket_cnt);
     if (STAMP && dbg_g) {  // a buffer of its own: nothing else in the kernel reads it
         const uint64_t t1 = rd_stamp(), r1 = rd_stamp_real();
         sm_comp += t1 - sm_mark;
@@ -1167,15 +683,10 @@ static int rd_mf_env(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// What the shipped kernel is built with (-DRD_MF_PRODUCT_OPT=n overrides; the diagnostic library selects at run time)
-#ifndef RD_MF_PRODUCT_OPT
-#define RD_MF_PRODUCT_OPT (RD_OPT_HALO | RD_OPT_B8)
-#endif
-
 // Launch parameters read once per process.  A function-local static: initialised exactly once, also when several
 // threads make their first launch together (handles may be used from several threads, rd_api.hip).
 struct rd_mf_params {
-    int dbg = 0, opt = RD_MF_PRODUCT_OPT, nbuf = 1, chunk_env = 0, per_cu_env = 0, n_cu = 256;
+    int dbg = 0, stamp = 0, chunk_env = 0, per_cu_env = 0, n_cu = 256;
     uint32_t stflags = 0;
     rd_mf_params() {
         chunk_env = rd_mf_env("RD_K1_CHUNK", 0);          // tuning knobs: results do not depend on them
@@ -1183,9 +694,8 @@ struct rd_mf_params {
 #ifdef RD_DIAG
         // timing ablations and A/B switches, wrong results for most of them: the diagnostic library only
         dbg = rd_mf_env("RD_K1_DEBUG", 0);
-        opt = rd_mf_env("RD_K1_OPT", RD_MF_PRODUCT_OPT);
-        nbuf = rd_mf_env("RD_K1_NBUF", 1) == 2 ? 2 : 1;
-        stflags = (uint32_t)rd_mf_env("RD_K1_STFLAGS", 0);
+        stamp = rd_mf_env("RD_K1_STAMPS", 0) ? 1 : 0;
+        stflags = (uint32_t)rd_mf_env("RD_K1_STFLAGS", 0) & (1u | 2u | 4u | 4096u);
 #endif
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1199,7 +709,7 @@ static const rd_mf_params &rd_mf_get_params() {
 }
 
 #ifdef RD_DIAG
-// stamps of the last RD_OPT_STAMP launch: RD_STAMP_WORDS uint64 per wave (diagnostic library only)
+// stamps of the last stamped launch: RD_STAMP_WORDS uint64 per wave (diagnostic library only)
 static uint64_t *g_stamp_buf = nullptr;
 static uint32_t g_stamp_waves = 0;
 extern "C" int rd_diag_read_stamps(uint64_t *out, uint32_t cap_waves, uint32_t *n_waves) {
@@ -1210,11 +720,10 @@ extern "C" int rd_diag_read_stamps(uint64_t *out, uint32_t cap_waves, uint32_t *
     if (n && hipMemcpy(out, g_stamp_buf, (size_t)n * RD_STAMP_WORDS * 8, hipMemcpyDeviceToHost) != hipSuccess) return RD_ERR_DEVICE;
     return RD_OK;
 }
-extern "C" int rd_diag_variant(int *dbg, int *opt, int *nbuf, uint32_t *stflags) {
+extern "C" int rd_diag_variant(int *dbg, int *stamp, uint32_t *stflags) {
     const rd_mf_params &P = rd_mf_get_params();
     if (dbg) *dbg = P.dbg;
-    if (opt) *opt = P.opt;
-    if (nbuf) *nbuf = P.nbuf;
+    if (stamp) *stamp = P.stamp;
     if (stflags) *stflags = P.stflags;
     return RD_OK;
 }
@@ -1227,21 +736,18 @@ struct rd_mf_launch_args {
     uint32_t *fix_list, fix_cap, *counters;
     hipStream_t st;
     hipEvent_t ev_start, ev_stop;
-    uint32_t stf_extra = 0;  // the self-fix variant's pending limit, or-ed into the kernel's stflags
-    bool self_fix = false;
-    const rd_mf_extra *extra = nullptr;  // fused-search variant
     uint32_t *bucket_cnt = nullptr;      // RD_DEMOD_FIX_BUCKETS
     uint32_t *chunk_out = nullptr;
     float *dbg_g;
 };
 
-template <int D, int NB, int OPT>
+template <int D, bool STAMP>
 static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
     const rd_mf_params &P = rd_mf_get_params();
     // persistent grid sized from the occupancy API (registers and LDS of the variant actually launched)
     static const int per_cu_occ = [] {
         int occ = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<D, NB, OPT>, RD_MF_WG, 0);
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_demod_mfma<D, STAMP>, RD_MF_WG, 0);
         return (e == hipSuccess && occ >= 1) ? (occ > 8 ? 8 : occ) : 2;
     }();
     // (three workgroups per CU instead of the four that fit: 4 % slower)
@@ -1262,11 +768,11 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
     const uint64_t max_wgs = (uint64_t)P.n_cu * per_cu;
     if (wgs > max_wgs) wgs = max_wgs;
     float *dbg = a.dbg_g;
-    if (OPT & RD_OPT_FSEARCH) dbg = (float *)a.extra;  // (the fused-search variant reads its extra arguments there)
-    else if (a.bucket_cnt && D == 0 && !(OPT & (RD_OPT_STAMP | RD_OPT_SELF))) dbg = (float *)a.bucket_cnt;
+    uint32_t stf = P.stflags;
+    if (a.bucket_cnt && D == 0 && !STAMP) { dbg = (float *)a.bucket_cnt; stf |= RD_STF_BUCKETS; }
     if (a.chunk_out) { a.chunk_out[0] = chunk; a.chunk_out[1] = (uint32_t)wgs * RD_MF_WAVES; }
 #ifdef RD_DIAG
-    if (OPT & RD_OPT_STAMP) {
+    if (STAMP) {
         const uint32_t nw = (uint32_t)wgs * RD_MF_WAVES;
         if (nw > g_stamp_waves || !g_stamp_buf) {
             if (g_stamp_buf) hipFree(g_stamp_buf);
@@ -1278,64 +784,50 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
     }
 #endif
     if (a.ev_start || a.ev_stop)
-        hipExtLaunchKernelGGL((k_demod_mfma<D, NB, OPT>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.ev_start,
-                              a.ev_stop, 0, a.lay, a.tps, a.total, chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags | a.stf_extra);
+        hipExtLaunchKernelGGL((k_demod_mfma<D, STAMP>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.ev_start,
+                              a.ev_stop, 0, a.lay, a.tps, a.total, chunk, a.fix_list, a.fix_cap, a.counters, dbg, stf);
     else
-        hipLaunchKernelGGL((k_demod_mfma<D, NB, OPT>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.lay, a.tps, a.total,
-                           chunk, a.fix_list, a.fix_cap, a.counters, dbg, P.stflags | a.stf_extra);
+        hipLaunchKernelGGL((k_demod_mfma<D, STAMP>), dim3((unsigned)wgs), dim3(RD_MF_WG), 0, a.st, a.lay, a.tps, a.total,
+                           chunk, a.fix_list, a.fix_cap, a.counters, dbg, stf);
 }
 
-void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t pend_limit,
-                          const rd_mf_extra *extra, uint32_t *chunk_out, uint32_t *bucket_cnt) {
+// Returns false when the fix-up entries went to the one global list although buckets were asked for (the stamped and
+// ablated variants of the diagnostic library keep the list): the caller then launches k_fixup as before.
+bool rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                          hipEvent_t ev_start, hipEvent_t ev_stop, float *dbg_g, uint32_t flags, uint32_t *chunk_out,
+                          uint32_t *bucket_cnt) {
     rd_mf_launch_args a;
-    a.extra = (flags & RD_DEMOD_FUSED_SEARCH) ? extra : nullptr;
-    a.bucket_cnt = (flags & RD_DEMOD_FIX_BUCKETS) && !dbg_g ? bucket_cnt : nullptr;
     a.chunk_out = chunk_out;
-    a.self_fix = (flags & RD_DEMOD_SELF_FIX) != 0;
-    a.stf_extra = a.self_fix ? ((pend_limit & 0xFFu) << 16) : 0u;
-    if (a.bucket_cnt) a.stf_extra |= RD_STF_BUCKETS;
+    a.bucket_cnt = (flags & RD_DEMOD_FIX_BUCKETS) && !dbg_g ? bucket_cnt : nullptr;
     a.lay = lay;
     a.tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
     a.total64 = (uint64_t)lay.n_streams * a.tps;
-    if (a.total64 == 0) return;
+    if (a.total64 == 0) return a.bucket_cnt != nullptr;
     a.total = (uint32_t)a.total64;
     a.fix_list = fix_list; a.fix_cap = fix_cap; a.counters = counters;
     a.st = st; a.ev_start = ev_start; a.ev_stop = ev_stop; a.dbg_g = dbg_g;
     if (dbg_g) {  // the test hook: raw filter outputs as well
-#ifdef RD_DIAG
-        if ((rd_mf_get_params().opt & RD_OPT_B8) != (RD_MF_PRODUCT_OPT & RD_OPT_B8)) {
-            rd_mf_launch_variant<3, 1, (RD_MF_PRODUCT_OPT ^ RD_OPT_B8)>(a);
-            return;
-        }
-#endif
-        rd_mf_launch_variant<3, 1, RD_MF_PRODUCT_OPT>(a);
-        return;
+        rd_mf_launch_variant<3, false>(a);
+        return false;
     }
 #ifdef RD_DIAG
     const rd_mf_params &P = rd_mf_get_params();
-    const int key = P.dbg * 1000 + P.nbuf * 100 + (P.opt | (a.extra ? RD_OPT_FSEARCH : a.self_fix ? RD_OPT_SELF : 0));  // (opt < 100)
-    switch (key) {
-#define RD_V(D, NB, O) case (D) * 1000 + (NB) * 100 + (O): rd_mf_launch_variant<D, NB, O>(a); return;
-        RD_V(0, 1, 0) RD_V(0, 1, 1) RD_V(0, 1, 2) RD_V(0, 1, 3) RD_V(0, 1, 4) RD_V(0, 1, 5) RD_V(0, 1, 6) RD_V(0, 1, 7)
-        RD_V(1, 1, 0) RD_V(1, 1, 1)
-        RD_V(2, 1, 0) RD_V(2, 1, 2) RD_V(2, 1, 4) RD_V(2, 1, 6)
-        RD_V(6, 1, 0) RD_V(6, 1, 2) RD_V(6, 1, 4) RD_V(6, 1, 6)
-        RD_V(4, 1, 0) RD_V(5, 1, 0) RD_V(7, 1, 0) RD_V(7, 1, 3) RD_V(9, 1, 0)
-        RD_V(1, 1, 4) RD_V(4, 1, 4) RD_V(5, 1, 4) RD_V(7, 1, 4) RD_V(9, 1, 4)
-        RD_V(10, 1, 0) RD_V(10, 1, 4) RD_V(11, 1, 0) RD_V(11, 1, 4)
-        RD_V(0, 1, 8) RD_V(0, 1, 10) RD_V(0, 1, 14) RD_V(7, 1, 10) RD_V(0, 1, 26) RD_V(1, 1, 10) RD_V(2, 1, 10) RD_V(6, 1, 10) RD_V(0, 1, 42) RD_V(0, 1, 74)
-        RD_V(0, 2, 0)
-#undef RD_V
-        default:
-            fprintf(stderr, "[rd diag] no kernel variant RD_K1_DEBUG=%d RD_K1_NBUF=%d RD_K1_OPT=%d is compiled in\n", P.dbg, P.nbuf, P.opt);
-            abort();
+    if (P.stamp || P.dbg) {
+        a.bucket_cnt = nullptr;   // (these variants keep the one fix-up list: the caller runs k_fixup on it, bounded by fix_cap)
+        if (P.stamp && P.dbg == 0) { rd_mf_launch_variant<0, true>(a); return false; }
+        switch (P.dbg) {
+            case 1: rd_mf_launch_variant<1, false>(a); return false;
+            case 2: rd_mf_launch_variant<2, false>(a); return false;
+            case 6: rd_mf_launch_variant<6, false>(a); return false;
+            case 7: rd_mf_launch_variant<7, false>(a); return false;
+            default:
+                fprintf(stderr, "[rd diag] no kernel variant RD_K1_DEBUG=%d RD_K1_STAMPS=%d is compiled in\n", P.dbg, P.stamp);
+                abort();
+        }
     }
-#else
-    if (a.extra) rd_mf_launch_variant<0, 1, (RD_MF_PRODUCT_OPT | RD_OPT_FSEARCH)>(a);
-    else if (a.self_fix) rd_mf_launch_variant<0, 1, (RD_MF_PRODUCT_OPT | RD_OPT_SELF)>(a);
-    else rd_mf_launch_variant<0, 1, RD_MF_PRODUCT_OPT>(a);
 #endif
+    rd_mf_launch_variant<0, false>(a);
+    return a.bucket_cnt != nullptr;
 }
 
 // Test hook (tests/test_gpu_mfma.py): run the kernel on host data, return the raw filter outputs g

@@ -9,16 +9,12 @@
 // counters[] slots (device uint32)
 // FIX: flagged runs; MATCH: preamble matches (= primary records); REC: second records of
 // block-boundary positions; PARSED: CRC-valid messages
-// OVF: the ordered tail could not hold this input (bit 0: a stream with more than RD_BUCKET matches, bit 1: more
-// records than the list has room for)
-enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_OVF = 5, RD_CNT_SELF = 6, RD_CNT_SLOTS = 8 };
-// RD_CNT_FIX: entries in the global fix-up list (k_fixup's input).  RD_CNT_SELF: groups' words the demod kernel
-// re-evaluated itself (self-fix, below); its per-wave contributions are added to word RD_SELF_WORD of the wave's
-// work-queue slot (32 cache lines instead of one) and summed into RD_CNT_SELF by the search kernel's first wave.
-#define RD_SELF_WORD 1
+// OVF: the one-launch tail could not hold this input (1: a stream with more matches than its list, 2: more records
+// than the output array has room for, 8: a group's fix-up bucket overflowed, 16: a workgroup gave up waiting for the
+// totals of the groups in front of it)
+enum { RD_CNT_FIX = 0, RD_CNT_MATCH = 1, RD_CNT_REC = 2, RD_CNT_TASKS = 3, RD_CNT_PARSED = 4, RD_CNT_OVF = 5, RD_CNT_SLOTS = 8 };
+// RD_CNT_FIX: entries in the global fix-up list (k_fixup's input; written by k_tail as the sum over its groups' buckets)
 // rd_launch_demod flags
-#define RD_DEMOD_SELF_FIX 1u   /* a wave re-evaluates the groups it flagged itself when it has run out of tiles: no k_fixup launch */
-#define RD_DEMOD_FUSED_SEARCH 2u   /* the preamble test runs inside the demod kernel (Davis shape, per-stream buckets) */
 #define RD_DEMOD_FIX_BUCKETS 4u    /* the fix-up entries go to per-group buckets (the one-launch tail, k_tail): fix_list =
                                       [groups][fix_cap] entries, bucket_cnt = [groups] counters, group = stream >> RD_FT_GSH */
 // The one-launch tail (rd_kernels.hip: k_tail): a workgroup owns RD_FT_STREAMS consecutive streams
@@ -30,15 +26,6 @@ struct rd_ft_bufs {
     uint32_t fix_bcap = 0;
     uint32_t bcap = 0;           // matches a stream's list in LDS holds (a multiple of 32, rd_host.h: rd_ord_bucket_cap)
     uint32_t *gstate = nullptr;  // [3][groups]: (seq << 20 | records), matches, fix-up entries per group
-};
-// What the fused-search variant of the demod kernel needs beyond its arguments (device memory, one per counter set;
-// the kernel receives its address in place of the test hook's output pointer)
-#define RD_WAVE_MATCHES 256  /* matches a demod wave keeps in its own list (16 on average at the bench workload, 70 at most) */
-struct rd_mf_extra {
-    int2 *wmatch;         // [demod wave][RD_WAVE_MATCHES] (stream, position): plain stores, no atomics in that kernel
-    uint32_t *wcount;     // [demod wave]: entries written (every wave of a launch writes its count, 0 included)
-    int32_t p_hi;         // last position to report (py:171-188: (n_blocks + 1) B - L)
-    int32_t pad;
 };
 // Behind the RD_CNT_SLOTS counters the host reads back: the demod kernel's work queues (chunks handed out beyond
 // the first one of every wave).  One counter word sustains ~90 atomics per microsecond, so there are RD_NQUEUE of
@@ -78,20 +65,17 @@ int rd_ensure_device_public(void);
 
 // --- launches (all asynchronous on `st`) ---
 // ev_start / ev_stop (optional): events that receive the kernel's own begin / end timestamps.
-// flags: RD_DEMOD_SELF_FIX; pend_limit (test hook, 0 = the kernel's own): entries a wave keeps before it falls back to the
-// global list.  Returns the flags the launched kernel honours (the round-1 VALU kernel of the diagnostic library: none).
-// extra (device address): required by RD_DEMOD_FUSED_SEARCH; chunk_out: receives the tiles per chunk the launch used
-// (the boundary pass of the reduced search needs it)
+// flags: RD_DEMOD_FIX_BUCKETS with bucket_cnt (the groups' entry counters; fix_list = [groups][fix_cap] then).  Returns the
+// flags the launched kernel honoured (the ablated kernels of the diagnostic library keep the one list: none).
+// chunk_out: receives the tiles per chunk the launch used and the number of waves
 uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t flags = 0, uint32_t pend_limit = 0,
-                     const rd_mf_extra *extra = nullptr, uint32_t *chunk_out = nullptr, uint32_t *bucket_cnt = nullptr);
-// The same stage with the FIR on the matrix pipe (rd_demod_mfma.hip); rd_launch_demod dispatches to it
-// unless RD_K1_IMPL=valu.  dbg_g (test hook): when given, the kernel also dumps g[tile][2048][2].
-void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t flags = 0,
+                         uint32_t *chunk_out = nullptr, uint32_t *bucket_cnt = nullptr);
+// The kernel itself (rd_demod_mfma.hip).  dbg_g (test hook): when given, the kernel also dumps g[tile][2048][2].
+// Returns true when the fix-up entries went to the buckets.
+bool rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, float *dbg_g = nullptr,
-                          uint32_t flags = 0, uint32_t pend_limit = 0, const rd_mf_extra *extra = nullptr,
-                          uint32_t *chunk_out = nullptr,    // chunk_out[0] = tiles per chunk, [1] = waves launched
-                          uint32_t *bucket_cnt = nullptr);  // RD_DEMOD_FIX_BUCKETS: the groups' entry counters
+                          uint32_t flags = 0, uint32_t *chunk_out = nullptr, uint32_t *bucket_cnt = nullptr);
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
@@ -102,39 +86,9 @@ void rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,
                      uint32_t *zero_next, hipStream_t st, uint32_t zero_words = RD_CNT_TOTAL, uint64_t expect = 0);
 // Search positions p in [p_lo, p_hi] of every stream's bit array (bits outside [0, n_bits) are 0).
-// smatch / scount (both or neither): the matches go to per-stream buckets instead of the one list (ordered tail)
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
-                      hipStream_t st, int32_t *smatch = nullptr, uint32_t *scount = nullptr,
-                      uint32_t *zero_next = nullptr, uint32_t zero_words = 0);
-// zero_next / zero_words (self-fix runs, which launch no k_fixup): the search kernel's first workgroup clears the
-// handle's next counter set and sums the demod waves' self-fix counts into RD_CNT_SELF
-// The ordered tail of the batch path (rd_kernels.hip): search into per-stream buckets, per-stream rank and dedupe,
-// RSSI / SNR, records written in the reference's order.  RD_BUCKET matches per stream at most.
-#define RD_BUCKET 32
-#define RD_OTASK_BYTES 32
-#define RD_ORD_LIST_STREAMS 8    /* streams whose surviving tasks form one dense list (one workgroup of k_classify_ord) */
-#define RD_ORD_SUPER 4           /* consecutive lists that k_rssi_ord deals out to its waves as one */
-struct rd_ord_bufs {
-    int32_t *smatch = nullptr;   // [n_streams][RD_BUCKET] positions
-    uint32_t *scount = nullptr;  // [n_streams] matches found (lives behind the counter set of the run: cleared with it)
-    void *tasks = nullptr;       // [lists][RD_ORD_LIST_STREAMS * 2 RD_BUCKET] entries of RD_OTASK_BYTES: one dense list per 8 streams
-    uint32_t *wgtot = nullptr;   // [2][lists] surviving tasks per list, matches per list; lists = ceil(n_streams / RD_ORD_LIST_STREAMS)
-};
-// rem (fused search): the demod kernel has done the preamble test; k_search_rem evaluates what it left out
-struct rd_rem_args {
-    const int2 *wmatch;        // the demod waves' own match lists (rd_mf_extra), scattered into the buckets here
-    const uint32_t *wcount;
-    uint32_t n_waves;          // waves of the demod launch
-    uint32_t chunk;            // tiles per chunk of the demod launch
-    const uint32_t *fix_list;  // the fix-up list k_fixup has just worked through
-    uint32_t fix_cap;
-    uint64_t expect_fix;       // the previous run's list length (grid size only)
-};
-int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
-                           const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
-                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop = nullptr,
-                           uint32_t *zero_next = nullptr, uint32_t zero_words = 0, const rd_rem_args *rem = nullptr);
+                      hipStream_t st);
 // The whole tail in one launch (k_tail): exact bits for the listed groups, search, slice with order and dedupe, RSSI /
 // SNR, final records.  seq: 1..4095, different from the previous launch on fb.gstate.  skip_fix: the bits are final.
 // Returns 1 when launched, 0 when the shape is not the one the kernel is built for.
@@ -188,6 +142,22 @@ struct rd_sb_args {
 };
 // 1 when the kernel was launched, 0 when the configuration is not one it is built for
 int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st);
+
+// The same for the complex-input branch (k_stream_block_cplx): one stream, complex128 ring, input from mapped host memory
+// as complex128 or (in_is_u8) as bytes through the LUT
+struct rd_sbc_args {
+    rd_devcfg cfg;
+    double *ring;             // [hdr 32 doubles][previous block][newest block]
+    const void *in;           // device address of the pinned input: B complex128 or 2B bytes
+    int in_is_u8;
+    const uint32_t *win_in;
+    uint32_t *win_out;
+    rd_packet *recs_host;     // mapped host memory: B + 1 records
+    uint32_t *cnt_host, *flag_host;
+    uint32_t seq;
+    long seen_before;
+};
+int rd_launch_stream_block_cplx(const rd_sbc_args &a, hipStream_t st);
 
 // complex128 input path (py:144-150): raw ring of interleaved doubles
 struct rd_cplx_layout {

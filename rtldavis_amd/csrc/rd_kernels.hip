@@ -1,21 +1,18 @@
-// rd_kernels.hip - gfx950 kernels of the rtldavis IQ -> bits -> packets path.
+// rd_kernels.hip - gfx950 kernels of the rtldavis IQ -> bits -> packets path other than the fused demod kernel
+// (rd_demod_mfma.hip).
 //
 // Reference stages (py = /root/reference/src/rtldavis/dsp.py, go = /root/reference/dsp/dsp.go):
-//   k_demod_bits   : LUT py:38-39 + rotate_fs4 py:46-49 + fir9 py:71-73 + discriminate
-//                    numerator py:89 + quantize py:98 + bit pack (go:105-113), fused; fp32 with
-//                    a rigorous guard band (rd_math.h) feeding
-//   k_fixup        : exact integer re-evaluation of guard-band runs
+//   k_tail         : everything behind the demod kernel in ONE launch (batch path, Davis shape): exact bits for the
+//                    listed groups, Demodulator._search py:171-188, ._slice py:190-246 incl. order, dedupe, RSSI / SNR
+//   k_fixup        : exact integer re-evaluation of the listed groups (every other shape, the streaming legacy path)
 //   k_search       : Demodulator._search py:171-188 (go:115-131) on packed bits, bit-parallel
-//   k_slice_rssi   : Demodulator._slice py:190-246 (call assignment, packing, the certain cases of
-//                    the per-call dedupe, RSSI/SNR windows), one wave per match
+//   k_classify + k_rssi_u8, k_slice_rssi : Demodulator._slice py:190-246 without the final order (the host orders)
+//   k_stream_block : one Demodulator.demodulate() call py:139-246 in one launch (streaming handle)
 //   k_parse_select / k_freq_err : Parser.parse front half, protocol.py:290-311 (opt-in)
 //   k_disc/k_filt  : float64 discriminate / fir9 values for the state mirrors py:133-134
 //   k_cplx_*       : the complex-input branch py:144-150 in float64
 //   stage kernels  : one float64 kernel per reference stage function
-//
-// HBM-bound scan: no MFMA (there is no dense contraction).  The input is read once with
-// 16-byte coalesced global->LDS loads; each lane then owns 32 consecutive samples so the
-// 9-tap window lives in registers and one lane emits one packed 32-bit word.
+//   k_demod_bits   : the round-1 demod kernel (FIR on the VALU), diagnostic library only (RD_K1_IMPL=valu)
 #include <algorithm>
 #include <cstdlib>
 
@@ -25,6 +22,7 @@
 #include "rd_math.h"
 #include "rd_mfma.h"
 
+#ifdef RD_DIAG   // the round-1 demod kernel: A/B runs only
 #define RD_WG 256
 #define RD_WAVES (RD_WG / 64)
 #define RD_LDS_WAVE (32 + RD_TILE_BYTES)  // 32 B halo + one 4 KiB tile, private to a wave
@@ -201,23 +199,26 @@ __global__ __launch_bounds__(RD_WG, 4) void k_demod_bits(rd_layout lay, uint32_t
     if (npend) rd_flush_pending(mypend, npend, fix_list, fix_cap, counters, lane);
 }
 
+#endif  // RD_DIAG (k_demod_bits)
+
 // Environment switches of this file, read once per process (function-local static: thread-safe first use).
 struct rd_k_params {
     int impl_mfma = 1, per_cu_valu = 7, dbg = 0, npk = RD_NPK_DEFAULT, slice_two = 1, search_cap = 32 / 4;
     rd_k_params() {
-        const char *e = getenv("RD_K1_IMPL");  // "valu": the round-1 demod kernel (FIR on the VALU) for A/B runs
-        impl_mfma = (e && e[0] == 'v') ? 0 : 1;
-        e = getenv("RD_K1_WGS_PER_CU");
-        per_cu_valu = e ? atoi(e) : 7;
-        if (per_cu_valu < 1 || per_cu_valu > 8) per_cu_valu = 7;
-        e = getenv("RD_SLICE_IMPL");  // "wave": the one-kernel slice on the batch path as well (A/B)
+        const char *e = getenv("RD_SLICE_IMPL");  // "wave": the one-kernel slice on the batch path as well (A/B)
         slice_two = (e && e[0] == 'w') ? 0 : 1;
         e = getenv("RD_K2_WGS_PER_CU");  // tuning knob of k_search
         search_cap = e ? atoi(e) : 32 / 4;
         if (search_cap < 1 || search_cap > 64) search_cap = 32 / 4;
 #ifdef RD_DIAG
-        e = getenv("RD_K1_DEBUG");  // timing ablations with garbage results: the diagnostic library only
+        e = getenv("RD_K1_IMPL");  // "valu": the round-1 demod kernel (FIR on the VALU) for A/B runs
+        impl_mfma = (e && e[0] == 'v') ? 0 : 1;
+        e = getenv("RD_K1_WGS_PER_CU");
+        per_cu_valu = e ? atoi(e) : 7;
+        if (per_cu_valu < 1 || per_cu_valu > 8) per_cu_valu = 7;
+        e = getenv("RD_K1_DEBUG");  // timing ablations with garbage results
         dbg = e ? atoi(e) : 0;
+        npk = RD_NPK_DEFAULT;
         e = getenv("RD_K1_NPK");    // packed FIR steps per output, for tuning sweeps
         if (e) npk = atoi(e);
 #endif
@@ -229,25 +230,19 @@ static const rd_k_params &rd_k_get_params() {
 }
 
 uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, hipStream_t st,
-                         hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t flags, uint32_t pend_limit, const rd_mf_extra *extra,
-                         uint32_t *chunk_out, uint32_t *bucket_cnt) {
+                         hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t flags, uint32_t *chunk_out, uint32_t *bucket_cnt) {
+#ifdef RD_DIAG
     const rd_k_params &P = rd_k_get_params();
-    if (P.impl_mfma) {
-        if (!extra) flags &= ~RD_DEMOD_FUSED_SEARCH;
-        if (flags & RD_DEMOD_FUSED_SEARCH) flags &= ~RD_DEMOD_SELF_FIX;  // (the reduced search reads the global fix-up list)
-        if (!bucket_cnt || (flags & (RD_DEMOD_SELF_FIX | RD_DEMOD_FUSED_SEARCH))) flags &= ~RD_DEMOD_FIX_BUCKETS;
-        rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, pend_limit, extra, chunk_out,
-                             bucket_cnt);
-        return flags & (RD_DEMOD_SELF_FIX | RD_DEMOD_FUSED_SEARCH | RD_DEMOD_FIX_BUCKETS);
-    }
-    const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
-    const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
-    const uint64_t total = (uint64_t)lay.n_streams * tps;
-    uint64_t wgs = (total + RD_WAVES - 1) / RD_WAVES;
-    // persistent grid: workgroups per CU (72 VGPRs and 18.5 KiB LDS admit 7); RD_K1_WGS_PER_CU overrides
-    const uint64_t max_wgs = 256ull * P.per_cu_valu;
-    if (wgs > max_wgs) wgs = max_wgs;
-    if (wgs == 0) return 0;
+    if (!P.impl_mfma) {
+        const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
+        const uint32_t rps = (lay.n_samples + RD_RUN - 1) / RD_RUN;
+        const uint64_t total = (uint64_t)lay.n_streams * tps;
+        uint64_t wgs = (total + RD_WAVES - 1) / RD_WAVES;
+        // persistent grid: workgroups per CU (72 VGPRs and 18.5 KiB LDS admit 7); RD_K1_WGS_PER_CU overrides
+        const uint64_t max_wgs = 256ull * P.per_cu_valu;
+        if (wgs > max_wgs) wgs = max_wgs;
+        if (wgs == 0) return 0;
+
     // With events given, the dispatch itself carries them (hipExtLaunchKernelGGL): its begin / end
     // timestamps, without the marker packets of hipEventRecord that idle the GPU for ~6 us each.
 #define RD_LAUNCH_K1(D, N)                                                                                          \
@@ -259,19 +254,22 @@ uint32_t rd_launch_demod(const rd_layout &lay, uint32_t *fix_list, uint32_t fix_
             hipLaunchKernelGGL((k_demod_bits<D, N>), dim3((unsigned)wgs), dim3(RD_WG), 0, st, lay, tps, rps,        \
                                fix_list, fix_cap, counters);                                                        \
     } while (0)
-#ifdef RD_DIAG
-    if (P.dbg == 1) { RD_LAUNCH_K1(1, RD_NPK_DEFAULT); return 0; }
-    if (P.dbg == 2) { RD_LAUNCH_K1(2, RD_NPK_DEFAULT); return 0; }
-    if (P.npk == 0) { RD_LAUNCH_K1(0, 0); return 0; }
-    if (P.npk == 2) { RD_LAUNCH_K1(0, 2); return 0; }
-    if (P.npk == 4) { RD_LAUNCH_K1(0, 4); return 0; }
-    if (P.npk == 6) { RD_LAUNCH_K1(0, 6); return 0; }
-    if (P.npk == 7) { RD_LAUNCH_K1(0, 7); return 0; }
-    if (P.npk == 9) { RD_LAUNCH_K1(0, 9); return 0; }
-#endif
-    RD_LAUNCH_K1(0, RD_NPK_DEFAULT);
+        if (P.dbg == 1) { RD_LAUNCH_K1(1, RD_NPK_DEFAULT); return 0; }
+        if (P.dbg == 2) { RD_LAUNCH_K1(2, RD_NPK_DEFAULT); return 0; }
+        if (P.npk == 0) { RD_LAUNCH_K1(0, 0); return 0; }
+        if (P.npk == 2) { RD_LAUNCH_K1(0, 2); return 0; }
+        if (P.npk == 4) { RD_LAUNCH_K1(0, 4); return 0; }
+        if (P.npk == 6) { RD_LAUNCH_K1(0, 6); return 0; }
+        if (P.npk == 7) { RD_LAUNCH_K1(0, 7); return 0; }
+        if (P.npk == 9) { RD_LAUNCH_K1(0, 9); return 0; }
+        RD_LAUNCH_K1(0, RD_NPK_DEFAULT);
 #undef RD_LAUNCH_K1
-    return 0;
+        return 0;
+    }
+#endif
+    if (!bucket_cnt) flags &= ~RD_DEMOD_FIX_BUCKETS;
+    const bool bucketed = rd_launch_demod_mfma(lay, fix_list, fix_cap, counters, st, ev_start, ev_stop, nullptr, flags, chunk_out, bucket_cnt);
+    return bucketed ? RD_DEMOD_FIX_BUCKETS : 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -402,28 +400,13 @@ __device__ __forceinline__ void rd_flush_matches(const rd_match *pend, uint32_t 
 
 // S_ > 0: compile-time symbol length / preamble length (register funnel with constant
 // shifts); S_ == 0: run-time cfg.S / cfg.P (words fetched per tap).
-// BKT: the matches of stream s go to smatch[s][slot], slot drawn from scount[s] (one counter per stream: the ordered
-// tail, k_classify_ord, takes one lane per slot); nothing is staged and nothing is left to flush at the end.
-template <int S_, int P_, uint64_t PRE_, bool BKT = false>
+template <int S_, int P_, uint64_t PRE_>
 __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t *bits, size_t bits_stride, int n_streams, long nwords,
                                                 long base, long groups_per_stream, long p_lo, long p_hi,
                                                 rd_devcfg cfg, rd_match *matches, uint32_t match_cap,
-                                                uint32_t *counters, int32_t *smatch = nullptr, uint32_t *scount = nullptr,
-                                                uint32_t *zero_next = nullptr, uint32_t zero_words = 0) {
+                                                uint32_t *counters) {
     __shared__ rd_match pend_all[RD_SEARCH_WAVES][RD_MATCH_PEND];
     const int lane = threadIdx.x & 63;
-    // With the demod kernel's self-fix there is no k_fixup launch in front of this kernel; its two side jobs are done
-    // here by the first workgroup: the counter set of the handle's NEXT run is cleared, and the per-queue counts of the
-    // words the demod kernel's waves re-evaluated themselves are summed for the host.
-    if (zero_next && blockIdx.x == 0) {
-        for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x) zero_next[i] = 0;
-        if (threadIdx.x < 64) {
-            uint32_t v = lane < RD_NQUEUE ? counters[RD_CNT_QUEUE0 + lane * RD_QUEUE_STRIDE + RD_SELF_WORD] : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-            if (lane == 0) counters[RD_CNT_SELF] = v;
-        }
-    }
     rd_match *pend = pend_all[threadIdx.x >> 6];
     uint32_t npend = 0;  // wave-uniform
     // a wave covers 64 consecutive lane-groups (128 positions each) of ONE stream, so the
@@ -537,7 +520,6 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
             for (int o = 0; o < RD_SEARCH_OUT; o++) {
                 uint32_t mm = m[o];
                 uint64_t any = __ballot(mm != 0);
-                if (BKT) any = 0;  // (handled for the four words together behind this loop)
                 while (any) {  // each round, every lane with matches left contributes its lowest one
                     const uint32_t nf = (uint32_t)__popcll(any);
                     if (npend + nf > RD_MATCH_PEND) {
@@ -557,41 +539,11 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
                     any = __ballot(mm != 0);
                 }
             }
-            if (BKT) {
-                // per-stream buckets: ONE returning atomic per wave-group that found anything (3 in 10 do), for all
-                // four output words of all lanes - a lane's slots follow those of the lanes below it
-                uint32_t mine = 0;
-#pragma unroll
-                for (int o = 0; o < RD_SEARCH_OUT; o++) mine += (uint32_t)__popc(m[o]);
-                if (__ballot(mine != 0)) {  // wave-uniform
-                    uint32_t incl = mine;
-#pragma unroll
-                    for (int sh = 1; sh < 64; sh <<= 1) {
-                        const uint32_t up = (uint32_t)__shfl_up((int)incl, sh, 64);
-                        if (lane >= sh) incl += up;
-                    }
-                    const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
-                    uint32_t slot0 = 0;
-                    if (lane == 0) slot0 = atomicAdd(&scount[s], tot);
-                    uint32_t slot = __builtin_amdgcn_readfirstlane(slot0) + incl - mine;
-#pragma unroll
-                    for (int o = 0; o < RD_SEARCH_OUT; o++) {
-                        uint32_t mm = m[o];
-                        while (mm) {  // (lane-divergent, a few iterations at most)
-                            const int bpos = __builtin_ctz(mm);
-                            mm &= mm - 1;
-                            if (slot < RD_BUCKET) smatch[(size_t)s * RD_BUCKET + slot] = (int32_t)(p0 + 32 * o + bpos);
-                            slot++;
-                        }
-                    }
-                }
-            }
         }
     }
     // End of kernel: the workgroup's leftovers leave through ONE atomic (every wave flushing
     // its own few entries made 8192 serialized atomics = 90 us of a 110 us kernel).  What is
     // left is issue-bound: 64 funnel shifts (v_alignbit_b32, 4-cycle class) per 128 positions.
-    if (BKT) return;
     __shared__ uint32_t left[RD_SEARCH_WAVES + 1];
     if (lane == 0) left[threadIdx.x >> 6] = npend;
     __syncthreads();
@@ -621,7 +573,7 @@ __global__ __launch_bounds__(64 * RD_SEARCH_WAVES) void k_search(const uint32_t 
 
 void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, long n_bits, long p_lo, long p_hi,
                       const rd_devcfg &cfg, rd_match *matches, uint32_t match_cap, uint32_t *counters,
-                      hipStream_t st, int32_t *smatch, uint32_t *scount, uint32_t *zero_next, uint32_t zero_words) {
+                      hipStream_t st) {
     if (p_hi < p_lo || n_streams == 0) return;
     const long base = (p_lo >> 5) << 5;  // floor to a word boundary (p_lo may be negative)
     const long nwords = (n_bits + 31) / 32;
@@ -632,19 +584,14 @@ void rd_launch_search(const uint32_t *bits, size_t bits_stride, int n_streams, l
     if (wgs > 256ull * cap) wgs = 256ull * cap;
     // the Davis configuration (protocol.py:68-76): 14 samples/symbol, preamble 1100101110001001
     // (bit m of the mask = symbol m -> 0x91D3)
-    if (smatch && scount && cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
-        hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull, true>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
-                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, smatch, scount,
-                           zero_next, zero_words);
-    else if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
+    if (cfg.S == 14 && cfg.P == 16 && cfg.pre_mask == 0x91D3ull)
         hipLaunchKernelGGL((k_search<14, 16, 0x91D3ull>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride,
-                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, nullptr, nullptr,
-                           zero_next, zero_words);
+                           n_streams, nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
     else
         hipLaunchKernelGGL((k_search<0, 0, 0>), dim3((unsigned)wgs), dim3(64 * RD_SEARCH_WAVES), 0, st, bits, bits_stride, n_streams,
-                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters, nullptr, nullptr, zero_next,
-                           zero_words);
+                           nwords, base, groups, p_lo, p_hi, cfg, matches, match_cap, counters);
 }
+
 
 // ------------------------------------------------------------------------------------------
 // k_slice_rssi: one WAVE per match.  Decides which call(s) report it (py:194), packs
@@ -1201,414 +1148,6 @@ __global__ __launch_bounds__(256) void k_rssi_u8(rd_layout lay, rd_devcfg cfg, c
         }
         if (lane == 0) { recs[rec].rssi = rssi; recs[rec].snr = snr; }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// The ordered tail (batch path, Davis shape): the records leave the device in the reference's order, per-call
-// duplicates already dropped - what rd_batch_results used to do on one host core (0.23 ms per batch: radix sort by
-// (stream, call, index % S, index), then the first-occurrence-wins dedupe of py:203-205).
-//   k_search<.., BKT>  : the matches of stream s land in smatch[s][0 .. scount[s])
-//   k_classify_ord     : 32 lanes per stream, one per match: call assignment and packet bytes as in k_classify, then -
-//                        every task of the stream sits in the same half-wave - the exact dedupe and the rank of each
-//                        surviving task by two short loops of lane broadcasts; per-stream counts, their prefix inside
-//                        the workgroup and the workgroup's total
-//   k_rssi_ord         : eight waves per workgroup list of k_classify_ord: adds the totals of the lists in front (at
-//                        most n_streams / 8 words), evaluates the RSSI / SNR windows of its tasks on the matrix pipe
-//                        as k_rssi_u8 does and writes each whole record at its final position
-// A stream with more than RD_BUCKET matches (or more records than the list holds) raises RD_CNT_OVF and the host
-// falls back to the unordered kernels above for that input.
-// ------------------------------------------------------------------------------------------
-struct rd_otask {   // 32 bytes
-    int32_t call, q;
-    uint32_t d[3];  // the packet's bytes (K_ = 80: ten of them)
-    int32_t stream;
-    uint32_t pad[2];
-};
-#define RD_ORD_WG_STREAMS RD_ORD_LIST_STREAMS                 /* streams per workgroup of k_classify_ord */
-#define RD_ORD_WG_TASKS (RD_ORD_WG_STREAMS * 2 * RD_BUCKET)   /* task entries per workgroup list */
-
-template <int S_, int K_>
-__global__ __launch_bounds__(32 * RD_ORD_WG_STREAMS) void k_classify_ord(const uint32_t *bits, size_t bits_stride, int nwords, rd_devcfg cfg,
-                                                      const int32_t *smatch, const uint32_t *scount, int n_streams,
-                                                      uint32_t bucket_limit, int n_calls, rd_otask *tasks,
-                                                      uint32_t *wgtot, uint32_t *counters) {
-    constexpr int NBITS = (K_ - 1) * S_ + 1;          // bits pos .. of the packet
-    constexpr int NU = (NBITS + 31) / 32;
-    constexpr int NW = NU + 1;
-    constexpr int NBYTES = (K_ + 7) / 8;
-    static_assert(K_ % 8 == 0 && NBYTES <= 12, "at most 12 packet bytes in a task entry");
-    static_assert(NW <= 36, "the load fence below names 36 words");
-    __shared__ uint32_t s_k[RD_ORD_WG_STREAMS], s_m[RD_ORD_WG_STREAMS];
-    // per stream (half-wave) and match: {flags, call b0, key 0, key 1, bytes[3], -}: read back with the same address in
-    // all 32 lanes (a broadcast), instead of six ds_bpermute per step of the loops below
-    __shared__ __attribute__((aligned(16))) uint32_t s_t[RD_ORD_WG_STREAMS][RD_BUCKET][8];
-    const int lane = threadIdx.x & 63, sub = lane & 31, grp = threadIdx.x >> 5;
-    const int stream = blockIdx.x * RD_ORD_WG_STREAMS + grp;
-    // the stream's count and this lane's slot of its bucket are loaded together (a slot past the count holds an old
-    // run's position or nothing: dropped below) - one memory round trip instead of two in front of the word loads
-    uint32_t count = stream < n_streams ? scount[stream] : 0u;
-    int pos = stream < n_streams ? smatch[(size_t)stream * RD_BUCKET + sub] : 0;
-    const uint32_t nmatch = count;
-    const bool ovf = count > bucket_limit;
-    if (ovf) count = 0;  // the host runs the unordered path on this input
-    const bool live = (uint32_t)sub < count;
-    if (!live) pos = 0;
-    // the words that hold the packet's symbols: ALL loads issued before the first use (the fence below) - taken a few
-    // at a time they cost this kernel a memory latency per batch
-    const uint32_t *w = bits + (size_t)(stream < n_streams ? stream : 0) * bits_stride;
-    const int wi0 = pos >> 5;
-    const uint32_t sh = (uint32_t)(pos & 31);
-    uint32_t W[36];
-#pragma unroll
-    for (int j = 0; j < 36; j++) {
-        const int wi = wi0 + j;
-        W[j] = (j < NW && live && wi >= 0 && wi < nwords) ? w[wi] : 0u;
-    }
-    asm volatile("" : "+v"(W[0]), "+v"(W[1]), "+v"(W[2]), "+v"(W[3]), "+v"(W[4]), "+v"(W[5]), "+v"(W[6]), "+v"(W[7]), "+v"(W[8]),
-                      "+v"(W[9]), "+v"(W[10]), "+v"(W[11]), "+v"(W[12]), "+v"(W[13]), "+v"(W[14]), "+v"(W[15]), "+v"(W[16]), "+v"(W[17]));
-    asm volatile("" : "+v"(W[18]), "+v"(W[19]), "+v"(W[20]), "+v"(W[21]), "+v"(W[22]), "+v"(W[23]), "+v"(W[24]), "+v"(W[25]),
-                      "+v"(W[26]), "+v"(W[27]), "+v"(W[28]), "+v"(W[29]), "+v"(W[30]), "+v"(W[31]), "+v"(W[32]), "+v"(W[33]),
-                      "+v"(W[34]), "+v"(W[35]));
-    // calls that report this position (py:194, q <= B), as in k_classify
-    const uint32_t pl = (uint32_t)(pos + cfg.L), bq = pl / (uint32_t)cfg.B, br = pl - bq * (uint32_t)cfg.B;
-    const int b0 = (int)bq - 1;
-    const int q0 = pos - ((b0 + 1) * cfg.B - cfg.L);
-    const bool ok0 = live && b0 >= 0 && b0 < n_calls;
-    const int b1 = b0 - 1, q1 = q0 + cfg.B;
-    const bool ok1 = live && br == 0 && b1 >= 0 && b1 < n_calls;
-    // the packet's bytes: byte bi = symbols 8 bi .. 8 bi + 7, first symbol = MSB (py:197-200)
-    uint32_t u[NU];
-#pragma unroll
-    for (int j = 0; j < NU; j++) u[j] = __builtin_amdgcn_alignbit(W[j + 1], W[j], sh);
-    uint32_t dw[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < K_; k++) {
-        const int bit = k * S_, bi = k >> 3;
-        const uint32_t b = (u[bit >> 5] >> (bit & 31)) & 1u;
-        dw[bi >> 2] |= b << (8 * (bi & 3) + 7 - (k & 7));
-    }
-    // keys: (call, phase, q), the order of py:171-188 inside a call; task 0 = (b0, q0), task 1 = (b0 - 1, q0 + B)
-    const uint32_t ph0 = (uint32_t)q0 % (uint32_t)S_, ph1 = (uint32_t)q1 % (uint32_t)S_;
-    const uint32_t k0 = (ph0 << 24) | (uint32_t)q0, k1 = (ph1 << 24) | (uint32_t)q1;  // q <= B < 2^24 (checked by the host)
-    {
-        uint4 *e = (uint4 *)s_t[grp][sub];
-        e[0] = uint4{(ok0 ? 1u : 0u) | (ok1 ? 2u : 0u), (uint32_t)b0, k0, k1};
-        e[1] = uint4{dw[0], dw[1], dw[2], 0u};
-    }
-    uint32_t maxc = count;
-    maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, 32, 64));
-    maxc = __builtin_amdgcn_readfirstlane(maxc);
-    // (a half-wave reads what the same wave wrote: LDS operations of a wave complete in order, no barrier needed)
-    // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205).
-    // Four entries per trip (broadcast reads, all eight issued before the first is used: a trip per entry waited for
-    // the LDS once per entry); the slots past a stream's count hold flags = 0 and match nothing.
-    bool dup0 = false, dup1 = false;
-    for (uint32_t j0 = 0; j0 < maxc; j0 += 4) {
-        uint4 a[4], d[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            a[u] = *(const uint4 *)s_t[grp][(j0 + u) & (RD_BUCKET - 1)];
-            d[u] = *(const uint4 *)(s_t[grp][(j0 + u) & (RD_BUCKET - 1)] + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int ob0 = (int)a[u].y;
-            // (equal keys = the same position reported twice - the fused search's reduced pass may do that: the copy
-            // in the lower bucket slot counts as the earlier one)
-            const bool lower = (int)(j0 + u) < sub;
-            if (d[u].x == dw[0] && d[u].y == dw[1] && d[u].z == dw[2]) {
-                if ((a[u].x & 1u) && ob0 == b0 && (a[u].z < k0 || (a[u].z == k0 && lower))) dup0 = true;
-                if ((a[u].x & 2u) && ob0 - 1 == b0 && (a[u].w < k0 || (a[u].w == k0 && lower))) dup0 = true;
-                if ((a[u].x & 1u) && ob0 == b1 && (a[u].z < k1 || (a[u].z == k1 && lower))) dup1 = true;
-                if ((a[u].x & 2u) && ob0 - 1 == b1 && (a[u].w < k1 || (a[u].w == k1 && lower))) dup1 = true;
-            }
-        }
-    }
-    const bool kept0 = ok0 && !dup0, kept1 = ok1 && !dup1;
-    s_t[grp][sub][0] = (kept0 ? 1u : 0u) | (kept1 ? 2u : 0u);
-    // pass 2: rank among the surviving tasks of the stream
-    uint32_t r0 = 0, r1 = 0;
-    for (uint32_t j0 = 0; j0 < maxc; j0 += 4) {
-        uint4 a[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) a[u] = *(const uint4 *)s_t[grp][(j0 + u) & (RD_BUCKET - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int ob0 = (int)a[u].y;
-            auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
-            if (a[u].x & 1u) { r0 += before(ob0, a[u].z, b0, k0) ? 1u : 0u; r1 += before(ob0, a[u].z, b1, k1) ? 1u : 0u; }
-            if (a[u].x & 2u) { r0 += before(ob0 - 1, a[u].w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, a[u].w, b1, k1) ? 1u : 0u; }
-        }
-    }
-    const int src0 = lane & 32;
-    const uint64_t m0 = __ballot(kept0), m1 = __ballot(kept1);
-    const uint32_t kept = (uint32_t)__popc((uint32_t)(m0 >> src0)) + (uint32_t)__popc((uint32_t)(m1 >> src0));
-    if (sub == 0) { s_k[grp] = kept; s_m[grp] = nmatch; }
-    if (ovf && sub == 0) atomicOr(&counters[RD_CNT_OVF], 1u);
-    __syncthreads();
-    // the workgroup's list: its streams' tasks one stream after the other, each stream's in rank order
-    uint32_t off = 0;
-#pragma unroll
-    for (int g = 0; g < RD_ORD_WG_STREAMS; g++) off += g < grp ? s_k[g] : 0u;
-    rd_otask *tk = tasks + (size_t)blockIdx.x * RD_ORD_WG_TASKS + off;
-    if (kept0) { rd_otask t = {b0, q0, {dw[0], dw[1], dw[2]}, stream, {0, 0}}; tk[r0] = t; }
-    if (kept1) { rd_otask t = {b1, q1, {dw[0], dw[1], dw[2]}, stream, {0, 0}}; tk[r1] = t; }
-    if (threadIdx.x == 0) {
-        // the list's totals: plain stores, summed by k_rssi_ord - one atomic per workgroup on the shared counter line
-        // cost 12 us here (a counter word takes ~90 atomics per microsecond, and there are n_streams / 8 workgroups)
-        uint32_t tot = 0, mt = 0;
-        for (int g = 0; g < RD_ORD_WG_STREAMS; g++) { tot += s_k[g]; mt += s_m[g]; }
-        wgtot[blockIdx.x] = tot;
-        wgtot[gridDim.x + blockIdx.x] = mt;
-    }
-}
-
-// k_rssi_ord deals RD_ORD_SUPER consecutive lists of k_classify_ord (32 streams) out to RD_ORD_RSSI_WAVES waves as
-// ONE list: wave w takes entries w, w + 32, ... - the same ~6 packets per wave as k_rssi_u8 and nearly as evenly
-// (8-stream lists dealt out one by one left the slowest wave with half as many again).  An entry's final position: the
-// totals of the lists in front (summed here: at most n_streams / 8 words, one round of loads) plus its index.
-#define RD_ORD_RSSI_WAVES (RD_ORD_SUPER * RD_ORD_LIST_STREAMS)
-__global__ __launch_bounds__(256, 4) void k_rssi_ord(rd_layout lay, rd_devcfg cfg, const rd_otask *tasks, const uint32_t *wgtot,
-                                                  int n_lists, int nbytes, rd_packet *recs, uint32_t rec_cap,
-                                                  uint32_t *counters) {
-    const int lane = threadIdx.x & 63;
-    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const int sup = gw / RD_ORD_RSSI_WAVES, wv = gw % RD_ORD_RSSI_WAVES;
-    const int list0 = sup * RD_ORD_SUPER;
-    if (list0 >= n_lists) return;
-    // What the first task needs comes first: the lists' lengths, the overflow flag and - speculatively - entry wv of
-    // the super-list's first list (it IS the wave's first task whenever that list holds more than wv entries: a list
-    // averages 46, a super-list has 32 waves).  The totals of the lists in front (eight predicated loads per lane
-    // cover 512 lists) are only needed when the first record is stored: their loads are issued behind these and
-    // summed after the first task's samples have been asked for.
-    uint32_t nl[RD_ORD_SUPER];
-#pragma unroll
-    for (int k = 0; k < RD_ORD_SUPER; k++) nl[k] = list0 + k < n_lists ? wgtot[list0 + k] : 0u;
-    const uint32_t ovf = counters[RD_CNT_OVF];
-    const rd_otask t_spec = tasks[(size_t)list0 * RD_ORD_WG_TASKS + wv];
-    rd_k_h8 Ahi[3], Alo[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        Ahi[d] = *(const rd_k_h8 *)g_rssi_taps.v[0][d][lane];
-        Alo[d] = *(const rd_k_h8 *)g_rssi_taps.v[1][d][lane];
-    }
-    uint32_t part = 0;
-    for (int base = 0; base < list0; base += 512) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = base + lane + 64 * k;
-            v[k] = i < list0 ? wgtot[i] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) part += v[k];
-    }
-    // the last super-list's first wave also leaves the run's totals for the host (records, matches)
-    const bool totals = list0 + RD_ORD_SUPER >= n_lists && wv == 0;
-    uint32_t mt = 0;
-    if (totals)
-        for (int i = lane; i < n_lists; i += 64) mt += wgtot[n_lists + i];
-    uint32_t n = 0;
-#pragma unroll
-    for (int k = 0; k < RD_ORD_SUPER; k++) n += nl[k];
-    n = __builtin_amdgcn_readfirstlane(n);
-    // entry e of the super-list = entry e - (lengths of the lists before it) of one of its lists
-    auto entry = [&](uint32_t e) -> const rd_otask * {
-        uint32_t k = 0, pre = 0;
-#pragma unroll
-        for (int j = 0; j < RD_ORD_SUPER - 1; j++)
-            if (k == (uint32_t)j && e >= pre + nl[j]) { pre += nl[j]; k = j + 1; }
-        return tasks + (size_t)(list0 + k) * RD_ORD_WG_TASKS + (e - pre);
-    };
-    auto view = [&](int stream) {
-        rd_stream_view v;
-        v.base = lay.iq + (size_t)stream * lay.stream_stride;
-        v.valid_from = lay.valid_from;
-        v.n = lay.n_samples;
-        return v;
-    };
-    auto job_of = [&](const rd_otask &t) {
-        return rd_rssi_prepare(view(__builtin_amdgcn_readfirstlane(t.stream)), __builtin_amdgcn_readfirstlane(t.call) * cfg.B, cfg,
-                               __builtin_amdgcn_readfirstlane(t.q), lane);
-    };
-    const bool work = !ovf && (uint32_t)wv < n;  // (overflow: the host discards this run's records)
-    rd_otask t_cur = t_spec, t_nxt = t_spec;
-    rd_rssi_job j_cur = {};
-    rd_rssi_data d_cur = {};
-    if (work) {
-        if ((uint32_t)wv >= __builtin_amdgcn_readfirstlane(nl[0])) t_cur = *entry((uint32_t)wv);
-        t_nxt = *entry((uint32_t)wv + RD_ORD_RSSI_WAVES < n ? wv + RD_ORD_RSSI_WAVES : wv);
-        j_cur = job_of(t_cur);
-        if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += (uint32_t)__shfl_xor((int)part, o, 64);
-    const uint32_t first = __builtin_amdgcn_readfirstlane(part);
-    if (totals) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mt += (uint32_t)__shfl_xor((int)mt, o, 64);
-        if (lane == 0) {
-            counters[RD_CNT_TASKS] = first + n;
-            counters[RD_CNT_MATCH] = mt;
-            if (first + n > rec_cap) counters[RD_CNT_OVF] = ovf | 2u;
-        }
-    }
-    if (!work) return;
-    for (uint32_t r = (uint32_t)wv; r < n; r += RD_ORD_RSSI_WAVES) {
-        const rd_otask t_now = t_cur;
-        const rd_rssi_job j_now = j_cur;
-        const rd_rssi_data d_now = d_cur;
-        if (r + RD_ORD_RSSI_WAVES < n) {
-            j_cur = job_of(t_nxt);
-            if (j_cur.ok) d_cur = rd_rssi_fetch(j_cur);
-        }
-        t_cur = t_nxt;
-        if (r + 2 * RD_ORD_RSSI_WAVES < n) t_nxt = *entry(r + 2 * RD_ORD_RSSI_WAVES);
-        double rssi = 0.0, snr = 0.0;
-        const int stream = __builtin_amdgcn_readfirstlane(t_now.stream), call = __builtin_amdgcn_readfirstlane(t_now.call),
-                  q = __builtin_amdgcn_readfirstlane(t_now.q);
-        if (j_now.ok) {
-            float noise, sig;
-            rd_rssi_block(j_now, d_now, Ahi, Alo, lane, noise, sig);
-            rd_rssi_finish(noise, sig, j_now.ns, j_now.pe, j_now.q, lane, rssi, snr);
-        } else {  // a window that reaches outside the stream: the fp32 path with its per-sample checks
-            rd_rssi_u8(view(stream), (long)call * cfg.B, cfg, (long)q, lane, rssi, snr);
-        }
-        const uint32_t at = first + r;
-        if (lane == 0 && at < rec_cap) {
-            uint4 *o = (uint4 *)&recs[at];
-            o[0] = uint4{(uint32_t)stream, (uint32_t)call, (uint32_t)q, (uint32_t)nbytes};
-            o[1] = uint4{t_now.d[0], t_now.d[1], t_now.d[2], 0u};
-            o[2] = uint4{0u, 0u, 0u, 0u};
-            recs[at].rssi = rssi;
-            recs[at].snr = snr;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_search_rem: what is left of the search when the demod kernel has done the preamble test itself
-// (RD_DEMOD_FUSED_SEARCH, rd_demod_mfma.hip: rd_mf_search_tile).  That kernel reports every position whose 8-word
-// window holds no word on the fix-up list and does not reach back across the start of a chunk of tiles.  Here, after
-// k_fixup, one lane per item:
-//   item < n_chunks       the chunk that starts at tile item * chunk, if it is not a stream's first tile: all positions
-//                         of the seven words in front of it (the demod kernel's lanes 0-6 of that tile report nothing)
-//   item - n_chunks < n   fix-up list entry: the positions of the eight words that end with the listed word whose
-//                         window reaches it (their bits may have changed)
-//   the rest              entry e of demod wave w's own match list (rd_mf_extra): moved into its stream's bucket
-// A position in the windows of two listed words is reported twice (rare: 8 k words of 35 M are listed for a group
-// inside the guard band): k_classify_ord's dedupe drops the copy (same call, same bytes, same key - the lower bucket
-// slot wins).
-// ------------------------------------------------------------------------------------------
-template <int S_, int P_, uint64_t PRE_>
-__global__ __launch_bounds__(256) void k_search_rem(const uint32_t *bits, size_t bits_stride, int nwords, uint32_t tps,
-                                                    uint32_t total_tiles, uint32_t chunk, const uint32_t *fix_list,
-                                                    uint32_t fix_cap, const uint32_t *counters, int p_hi, int32_t *smatch,
-                                                    uint32_t *scount, const int2 *wmatch, const uint32_t *wcount,
-                                                    uint32_t n_waves) {
-    const uint32_t n_chunks = (total_tiles + chunk - 1) / chunk;
-    uint32_t n_fix = counters[RD_CNT_FIX];
-    if (n_fix > fix_cap) n_fix = fix_cap;  // (overflow: the host re-evaluates everything and searches in full)
-    const uint32_t n_list = n_chunks + n_fix;
-    const uint32_t items = n_list + n_waves * 64;  // 64 lanes per demod wave's list, whatever its length
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < items; item += gridDim.x * blockDim.x) {
-        uint32_t s;
-        int w_first, n_pos, need = -1, first_v = 0;
-        if (item >= n_list) {  // a demod wave's own list (a wave of this kernel = one list: its count is one broadcast load)
-            const uint32_t wv = (item - n_list) / 64;
-            const uint32_t cnt = wcount[wv];
-            for (uint32_t e = (item - n_list) % 64; e < cnt; e += 64) {
-                const int2 mp = wmatch[(size_t)wv * RD_WAVE_MATCHES + e];
-                const uint32_t slot = atomicAdd(&scount[mp.x], 1u);
-                if (slot < RD_BUCKET) smatch[(size_t)mp.x * RD_BUCKET + slot] = mp.y;
-            }
-            continue;
-        }
-        if (item < n_chunks) {
-            const uint32_t g = item * chunk;
-            s = g / tps;
-            const uint32_t ti = g - s * tps;
-            if (ti == 0) continue;
-            w_first = (int)(ti * (RD_TILE_SAMPLES / 32)) - 7;
-            n_pos = 7;
-        } else {
-            const uint32_t widx = fix_list[item - n_chunks] >> 4;
-            s = widx / (uint32_t)bits_stride;
-            need = (int)(widx - s * (uint32_t)bits_stride);
-            w_first = need - 7;
-            n_pos = 8;
-            // The first word of a chunk is always on the list (its first group has no predecessors in its wave): the
-            // seven words in front of it belong to that chunk's boundary item above - here only the word itself, or
-            // every match next to a chunk start would be reported twice and fill its stream's bucket.
-            const uint32_t wpt = RD_TILE_SAMPLES / 32;
-            if ((uint32_t)need % wpt == 0 && need > 0 && (s * tps + (uint32_t)need / wpt) % chunk == 0) first_v = 7;
-        }
-        const uint32_t *w = bits + (size_t)s * bits_stride;
-        uint32_t r[15];
-#pragma unroll
-        for (int j = 0; j < 15; j++) {
-            const int wi = w_first + j;
-            r[j] = (wi >= 0 && wi < nwords) ? w[wi] : 0u;
-        }
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            const int pw = w_first + v;
-            if (v < first_v || v >= n_pos || pw < 0) continue;
-            uint32_t m = 0xFFFFFFFFu, any = 0;
-#pragma unroll
-            for (int k = 0; k < P_; k++) {
-                const int wj = (k * S_) >> 5, sh = (k * S_) & 31;
-                const uint32_t x = sh ? __builtin_amdgcn_alignbit(r[v + wj + 1], r[v + wj], sh) : r[v + wj];
-                if ((PRE_ >> k) & 1) m &= x; else any |= x;
-            }
-            m &= ~any;
-            while (m) {
-                const int b = __builtin_ctz(m);
-                m &= m - 1;
-                const int p = 32 * pw + b;
-                if (p > p_hi) continue;
-                if (need >= 0 && pw + ((b + (P_ - 1) * S_) >> 5) < need) continue;  // its window ends before the listed word
-                const uint32_t slot = atomicAdd(&scount[s], 1u);
-                if (slot < RD_BUCKET) smatch[(size_t)s * RD_BUCKET + slot] = p;
-            }
-        }
-    }
-}
-
-// returns 1 when the ordered tail was launched (records: final, RD_CNT_TASKS of them from index 0), 0 when the
-// shape is not the one it is built for (the caller then uses rd_launch_search + rd_launch_slice)
-int rd_launch_tail_ordered(const rd_layout &lay, const uint32_t *bits, size_t bits_stride, long n_bits, long p_lo, long p_hi,
-                           const rd_devcfg &cfg, int n_calls, const rd_ord_bufs &ob, uint32_t bucket_limit, rd_packet *recs,
-                           uint32_t rec_cap, uint32_t *counters, hipStream_t st, hipEvent_t ev_stop, uint32_t *zero_next,
-                           uint32_t zero_words, const rd_rem_args *rem) {
-    if (!(cfg.S == 14 && cfg.P == 16 && cfg.K == 80 && cfg.pre_mask == 0x91D3ull) || n_bits >= (1l << 30) || cfg.B >= (1 << 24) ||
-        !ob.smatch || lay.n_streams <= 0)
-        return 0;
-    if (rem) {  // the demod kernel has searched: the windows around the fix-up list's words and the chunk starts are left
-        const uint32_t tps = (lay.n_samples + RD_TILE_SAMPLES - 1) / RD_TILE_SAMPLES;
-        const uint32_t total = (uint32_t)lay.n_streams * tps;
-        const uint64_t items = (uint64_t)(total + rem->chunk - 1) / rem->chunk + std::max<uint64_t>(rem->expect_fix + rem->expect_fix / 4, 4096) +
-                               (uint64_t)rem->n_waves * 64;
-        const uint32_t wgs = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL((k_search_rem<14, 16, 0x91D3ull>), dim3(wgs), dim3(256), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32),
-                           tps, total, rem->chunk, rem->fix_list, rem->fix_cap, counters, (int)p_hi, ob.smatch, ob.scount,
-                           rem->wmatch, rem->wcount, rem->n_waves);
-    } else {
-        rd_launch_search(bits, bits_stride, lay.n_streams, n_bits, p_lo, p_hi, cfg, nullptr, 0, counters, st, ob.smatch, ob.scount,
-                         zero_next, zero_words);
-    }
-    const uint32_t cg = (uint32_t)(lay.n_streams + RD_ORD_WG_STREAMS - 1) / RD_ORD_WG_STREAMS;
-    hipLaunchKernelGGL((k_classify_ord<14, 80>), dim3(cg), dim3(32 * RD_ORD_WG_STREAMS), 0, st, bits, bits_stride, (int)((n_bits + 31) / 32), cfg,
-                       ob.smatch, ob.scount, lay.n_streams, bucket_limit < RD_BUCKET ? bucket_limit : (uint32_t)RD_BUCKET, n_calls,
-                       (rd_otask *)ob.tasks, ob.wgtot, counters);
-    const uint32_t rg = (((cg + RD_ORD_SUPER - 1) / RD_ORD_SUPER) * RD_ORD_RSSI_WAVES + 3) / 4;
-    if (ev_stop)
-        hipExtLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, nullptr, ev_stop, 0, lay, cfg, (const rd_otask *)ob.tasks,
-                              ob.wgtot, (int)cg, cfg.nbytes, recs, rec_cap, counters);
-    else
-        hipLaunchKernelGGL(k_rssi_ord, dim3(rg), dim3(256), 0, st, lay, cfg, (const rd_otask *)ob.tasks, ob.wgtot, (int)cg,
-                           cfg.nbytes, recs, rec_cap, counters);
-    return 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2568,6 +2107,159 @@ int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st) {
         return 0;
     const size_t lds = 32 + 2 * (size_t)c.B + (size_t)(2 * c.B / 32) * 4 + ((size_t)c.B + 1) * 4;
     hipLaunchKernelGGL((k_stream_block<14, 16, 0x91D3ull, 80>), dim3((unsigned)n_streams), dim3(RD_SB_THREADS), lds, st, a);
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_stream_block_cplx: the same ONE launch for the complex-input branch (py:144-150) - what pyrtlsdr's sdr.stream()
+// feeds the live receiver (/root/reference/src/rtldavis/runners/rtlsdr.py:100-103).  Single stream; the raw ring holds
+// complex128 [hdr 16][previous block][newest block]; the new block comes from the slot's mapped host buffer as
+// complex128 (16 bytes per sample) or - a uint8 block on a handle that has seen complex input - as bytes through the
+// LUT (py:26,38-39).  Signs from a float64 sum in tap order, as k_cplx_bits (rd_f_f64): a thread keeps the 17 samples
+// its 8-sample group needs in registers.  Window, search, slice and the flag protocol are k_stream_block's; the RSSI /
+// SNR windows are rd_rssi_f64's.  block_size <= 8192 (eight 16-byte pieces per thread in the roll).
+// ------------------------------------------------------------------------------------------
+template <int S_, int P_, uint64_t PRE_, int K_>
+__global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block_cplx(rd_sbc_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sb_lds[];
+    const int B = a.cfg.B, nwin = (2 * B) / 32, nbw = B / 32;
+    uint32_t *s_win = (uint32_t *)sb_lds;           // the 2 B-bit window
+    int32_t *s_match = (int32_t *)(s_win + nwin);   // B + 1 positions
+    __shared__ uint32_t s_nm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *ring = a.ring;                          // [hdr 32 doubles][previous block 2 B][newest block 2 B]
+    uint4 *r_hdr = (uint4 *)ring, *r_prev = (uint4 *)(ring + 32), *r_cur = (uint4 *)(ring + 32 + 2 * (size_t)B);  // one uint4 = one sample
+    const bool have_hist = a.seen_before > 0;
+    if (tid == 0) s_nm = 0;
+    // ---- 0: the roll (py:140,154), every load before the first store ----
+    constexpr int PER = 8192 / RD_SB_THREADS;
+    uint4 nw[PER], oc[PER], ph = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + RD_SB_THREADS * k;
+        nw[k] = uint4{0, 0, 0, 0}; oc[k] = uint4{0, 0, 0, 0};
+        if (i < B) {
+            if (a.in_is_u8) {  // py:26,38-39
+                const uint8_t *q = (const uint8_t *)a.in + 2 * (size_t)i;
+                const double re = ((double)q[0] - 127.4) / 127.6, im = ((double)q[1] - 127.4) / 127.6;
+                const uint2 rb = __builtin_bit_cast(uint2, re), ib = __builtin_bit_cast(uint2, im);
+                nw[k] = uint4{rb.x, rb.y, ib.x, ib.y};
+            } else {
+                nw[k] = ((const uint4 *)a.in)[i];  // pinned host memory
+            }
+            if (have_hist) oc[k] = r_cur[i];
+        }
+    }
+    if (have_hist && tid < 16) ph = r_prev[B - 16 + tid];  // the old previous block's last 16 samples
+    const uint32_t *win_in = a.win_in;
+    uint32_t oldw = 0;
+    if (tid < nbw) oldw = win_in[nbw + tid];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + RD_SB_THREADS * k;
+        if (i < B) {
+            r_cur[i] = nw[k];
+            if (have_hist) r_prev[i] = oc[k];
+        }
+    }
+    if (have_hist && tid < 16) r_hdr[tid] = ph;
+    if (tid < nbw) s_win[tid] = oldw;
+    __syncthreads();   // (the ring stores above are read below by the whole workgroup: same CU, workgroup scope)
+    // ---- 1: sign bits in float64, one 8-sample group per thread (py:46-98; taps summed in order m = 0..8) ----
+    rd_cplx_view v;
+    v.base = ring + 32 + 2 * (size_t)B;
+    v.valid_from = a.seen_before <= 0 ? 0 : a.seen_before == 1 ? -(long)B : -(long)(B + 16);
+    v.n = B;
+    for (int g = tid; g < B / 8; g += RD_SB_THREADS) {
+        const long t0 = 8 * (long)g;
+        const double c[9] = {RD_C0, RD_C1, RD_C2, RD_C3, RD_C4, RD_C3, RD_C2, RD_C1, RD_C0};
+        rd_d2 y[17];
+#pragma unroll
+        for (int i = 0; i < 17; i++) y[i] = rd_sample_f64(v, t0 - 10 + i);
+        uint32_t byte = 0;
+        rd_d2 prev = {0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 9; j++) {  // f[t0 - 1 + j]
+            rd_d2 f = {0.0, 0.0};
+            if (t0 - 1 + j >= v.valid_from) {
+#pragma unroll
+                for (int m = 0; m < 9; m++) {
+                    f.x += c[m] * y[j + m].x;
+                    f.y += c[m] * y[j + m].y;
+                }
+            }
+            if (j > 0) byte |= rd_signbit_f64(rd_disc_f64(prev, f)) << (j - 1);
+            prev = f;
+        }
+        ((uint8_t *)(s_win + nbw))[g] = (uint8_t)byte;
+    }
+    __syncthreads();
+    // ---- 2: the window goes out for the state mirrors (rd_copy_quantized) and the next call ----
+    for (int i = tid; i < nwin; i += RD_SB_THREADS) a.win_out[i] = s_win[i];
+    // ---- 3: search, one 32-position word per thread; positions 0 .. B ----
+    for (int o = tid; o <= nbw; o += RD_SB_THREADS) {
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < P_; k++) {
+            const uint32_t x = rd_lds_bits32(s_win, nwin, 32 * o + k * S_);
+            m &= ((PRE_ >> k) & 1) ? x : ~x;
+        }
+        if (o == nbw) m &= 1u;  // position B only
+        while (m) {
+            const int bpos = __builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t slot = atomicAdd(&s_nm, 1u);
+            s_match[slot] = 32 * o + bpos;  // (at most B + 1 of them)
+        }
+    }
+    __syncthreads();
+    const uint32_t nm = s_nm;
+    // ---- 4: slice + RSSI / SNR, one wave per match ----
+    rd_packet *recs = a.recs_host;
+    for (uint32_t i = (uint32_t)wave; i < nm; i += RD_SB_THREADS / 64) {
+        const int pos = __builtin_amdgcn_readfirstlane(s_match[i]);
+        uint32_t byte = 0;
+        bool same_prev = true, same_next = true;
+        for (int r = 0; r * 64 < K_; r++) {
+            const int k = 64 * r + lane;
+            const uint32_t tri = k < K_ ? rd_lds_bits32(s_win, nwin, pos - 1 + k * S_) : 0u;
+            const uint64_t mp = __ballot((tri & 1u) != 0), mm = __ballot((tri & 2u) != 0), mn = __ballot((tri & 4u) != 0);
+            same_prev &= mp == mm;
+            same_next &= mn == mm;
+            const int bi = lane - 8 * r;
+            if (bi >= 0 && bi < 8) {
+                const int have = K_ - 8 * lane;
+                const uint32_t rev = __builtin_bitreverse32((uint32_t)((mm >> (8 * bi)) & 0xFF)) >> 24;
+                byte = have >= 8 ? rev : have > 0 ? rev >> (8 - have) : 0u;
+            }
+        }
+        const uint32_t phs = (uint32_t)pos % (uint32_t)S_;
+        const bool prev_first = S_ == 1 || phs != 0, next_first = S_ > 1 && phs == S_ - 1;
+        const bool superseded = (same_prev && pos >= 1 && prev_first) || (same_next && pos + 1 <= B && next_first);
+        if (superseded) {
+            rd_store_void(nullptr, &recs[i], lane);
+            continue;
+        }
+        double rssi = 0.0, snr = 0.0;
+        rd_rssi_f64(v, 0, a.cfg, (long)pos, lane, rssi, snr);
+        rd_store_record(nullptr, &recs[i], lane, 0, (long)a.seen_before, (long)pos, a.cfg.nbytes, byte, rssi, snr);
+    }
+    // ---- 5: count, fence, flag ----
+    __syncthreads();
+    if (tid == 0) {
+        a.cnt_host[0] = nm;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: records and count before the flag
+        __hip_atomic_store(&a.flag_host[0], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int rd_launch_stream_block_cplx(const rd_sbc_args &a, hipStream_t st) {
+    const rd_devcfg &c = a.cfg;
+    if (!(c.S == 14 && c.P == 16 && c.K == 80 && c.pre_mask == 0x91D3ull) || c.L != 2 * c.B || c.B % 32 || c.B < 2048 || c.B > 8192)
+        return 0;
+    const size_t lds = (size_t)(2 * c.B / 32) * 4 + ((size_t)c.B + 1) * 4;
+    hipLaunchKernelGGL((k_stream_block_cplx<14, 16, 0x91D3ull, 80>), dim3(1), dim3(RD_SB_THREADS), lds, st, a);
     return 1;
 }
 

@@ -17,7 +17,7 @@ import logging
 import math
 import os
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
@@ -214,6 +214,29 @@ class Demodulator:
         n = C.c_int(0)
         rc = _lib.lib().rd_demod_fetch(self._handle(), self._recs, self._cap, C.byref(n))
         return self._take(rc, n)
+
+    # --- zero-copy input: blocks that already lie in a producer's buffer ---
+    def register_input(self, buf: Optional[np.ndarray]) -> None:
+        """Pin a producer-owned uint8 buffer (e.g. ``rtldavis_amd.ring.BlockRing.data``) and map it into the device;
+        ``submit_from`` then launches on blocks inside it without copying them.  None unregisters.  The buffer must
+        outlive the registration."""
+        if buf is None:
+            _lib.check(_lib.lib().rd_demod_register_input(self._handle(), None, 0))
+            self._ext = None
+            return
+        a = np.asarray(buf)
+        if a.dtype != np.uint8 or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("register_input needs a contiguous uint8 buffer")
+        _lib.check(_lib.lib().rd_demod_register_input(self._handle(), a.ctypes.data, a.size))
+        self._ext = a   # (keeps the mapping alive)
+
+    def submit_from(self, offset: int, count: int, is_complex: bool = False) -> None:
+        """``submit`` for the block at ``offset`` bytes into the registered buffer: ``count`` = 2 * block_size bytes, or
+        block_size complex128 samples.  The block must stay untouched until its ``fetch()`` has returned."""
+        if count != (self.cfg.block_size if is_complex else 2 * self.cfg.block_size):
+            logger.error(f"Incompatible array sizes: count={count}, block_size={self.cfg.block_size}")
+            raise ValueError("Incompatible array sizes")
+        _lib.check(_lib.lib().rd_demod_submit_from(self._handle(), int(offset), int(count), 1 if is_complex else 0))
 
     @property
     def inflight(self) -> int:

@@ -54,16 +54,19 @@ REFERENCE_PACKAGE = "rtldavis"
 def reference_parser_factory(station_id: Optional[int], symbol_length: int) -> Callable[[], object]:
     """``lambda: protocol.Parser(symbol_length=..., station_id=...)`` (worker.py:29) with ``<package>.dsp`` swapped
     for ``rtldavis_amd.dsp`` first - what INTEGRATION.md section 2 adds to the reference's ``__init__``; done here
-    as well so that the entry point works on an unmodified checkout.  The swap must precede the first import of
-    ``<package>.protocol`` in this process (its ``from . import dsp`` binds the module once)."""
+    as well so that the entry point works on an unmodified checkout, whether or not ``<package>.protocol`` has been
+    imported already (the forked child of runners/rtlsdr.py inherits it: its ``dsp`` name is rebound)."""
     def make():
         pkg = REFERENCE_PACKAGE
         importlib.import_module(pkg)
         sys.modules[pkg + ".dsp"] = dsp
         protocol = importlib.import_module(pkg + ".protocol")
+        # runners/rtlsdr.py:6 imports `protocol` before it starts this worker, and under the fork start method the child
+        # inherits that module bound to the reference's own dsp.  protocol.py uses `dsp` through module-global lookups at
+        # call time only (dsp.PacketConfig in new_packet_config, dsp.Demodulator in Parser.__post_init__), so rebinding
+        # the name is all the swap needs (ADVICE r3)
         if getattr(protocol, "dsp", dsp) is not dsp:
-            raise RuntimeError(f"{pkg}.protocol was imported before the dsp swap: import rtldavis_amd.worker first, "
-                               "or set RTLDAVIS_BACKEND=hip as INTEGRATION.md section 2 describes")
+            protocol.dsp = dsp
         return protocol.Parser(symbol_length=symbol_length, station_id=station_id)
     return make
 
@@ -136,6 +139,87 @@ def worker_loop(data_queue, result_queue, parser_factory: Callable[[], object],
             logger.error(f"Error in DSP loop: {e}")
     if pending:
         finish()
+
+
+def ring_worker_main(ring_name: str, result_queue, station_id: Optional[int], symbol_length: int, log_level: int) -> None:
+    """``worker_main`` with the data queue replaced by a shared-memory ring (``rtldavis_amd.ring.BlockRing``): the
+    ``Process`` target for a runner whose producer calls ``ring.put(samples)`` where runners/rtlsdr.py:100-103 calls
+    ``data_queue.put(samples)``."""
+    from .ring import BlockRing
+    ring = BlockRing.attach(ring_name)
+    try:
+        ring_worker_loop(ring, result_queue, reference_parser_factory(station_id, symbol_length), log_level)
+    finally:
+        ring.close()
+
+
+def ring_worker_loop(ring, result_queue, parser_factory: Callable[[], object], log_level: int = logging.INFO,
+                     poll_s: float = 1.0) -> None:
+    """The loop of worker.worker_main (worker.py:18-58) on blocks that lie in a shared-memory ring: no pickle, no
+    pipe, and no copy on this side either - the ring's segment is registered with the device
+    (``Demodulator.register_input``) and every block is launched on where the producer wrote it (``submit_from``).
+    As in ``worker_loop`` a block is fetched and parsed before the next one is submitted (``Parser.parse`` reads the
+    demodulator's state of the block it was given, protocol.py:304-311); its slot goes back to the producer then.
+    ``ring.stop()`` on the producer's side plays the ``None`` sentinel (worker.py:40-42)."""
+    from .ring import KIND_C128, STOP
+    logging.basicConfig(level=log_level, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    logger = logging.getLogger("rtldavis.worker")
+    logger.info("DSP worker process started (shared-memory ring)")
+    try:
+        p = parser_factory()
+        dem = p.demodulator
+        dem.register_input(ring.data)
+    except Exception as e:  # worker.py:30-32
+        logger.exception(f"Failed to initialize worker: {e}")
+        return
+    pending = False  # a block is on the GPU, its packets not yet fetched, its slot not yet released
+
+    def finish() -> None:
+        nonlocal pending
+        try:
+            for msg in p.parse(dem.fetch()):
+                result_queue.put(msg)
+        except Exception as e:  # worker.py:56-58: log, drop the block, go on
+            logger.error(f"Error in DSP loop: {e}")
+            try:
+                while getattr(dem, "inflight", 0):
+                    dem.fetch()
+            except Exception:
+                try:
+                    dem.reset()
+                except Exception as e2:
+                    logger.error(f"Error in DSP loop: demodulator reset failed: {e2}")
+        ring.release()
+        pending = False
+
+    try:
+        while True:
+            try:
+                item = ring.get(taken=1 if pending else 0, timeout=0.0 if pending else poll_s)
+            except KeyboardInterrupt:
+                break
+            if pending:
+                finish()       # (a block that arrived meanwhile waits in its slot: nothing is lost)
+            if item is STOP:
+                # (blocks committed before stop() are still handed out first: get() says STOP only when drained)
+                logger.info("Worker received stop signal")
+                break
+            if item is None:
+                continue
+            _slot, offset, kind, count = item
+            try:
+                dem.submit_from(offset, count, kind == KIND_C128)
+                pending = True
+            except Exception as e:
+                logger.error(f"Error in DSP loop: {e}")
+                ring.release()
+        if pending:
+            finish()
+    finally:
+        try:
+            dem.register_input(None)
+        except Exception:
+            pass
 
 
 class _StreamView:

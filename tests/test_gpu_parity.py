@@ -876,9 +876,9 @@ def _records_of_child(tmp_path, n_seeds, env_extra, name):
 
 @pytest.mark.gpu
 def test_ordered_tail_equals_the_unordered_kernels_plus_host_ordering(dsp, batchmod, tmp_path):
-    """The batch path's default tail orders and dedupes on the device (k_search into per-stream buckets,
-    k_classify_ord, k_rssi_ord: dsp.py:171-188 order, dsp.py:203-205 first occurrence wins); RD_TAIL_IMPL=legacy is
-    the previous form - unordered kernels, radix sort and dedupe on the host.  Same records, field for field."""
+    """The batch path's default tail orders and dedupes on the device (k_tail: dsp.py:171-188 order, dsp.py:203-205
+    first occurrence wins); RD_TAIL_IMPL=legacy is the form every other shape takes - separate kernels, radix sort and
+    dedupe on the host.  Same records, field for field (the child process keeps the two forms' environments apart)."""
     seeds = list(range(40))
     raw = synth.synth_streams(seeds)
     bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
@@ -941,68 +941,6 @@ def test_pipelined_completion_returns_the_same_packets(dsp, batchmod, golden_str
     bds[2].close()                            # destroyed while waiting for an adopter
     bds[0].run()
     check(bds[0], groups[0])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"RD_FIXUP_IMPL": "self"}, {"RD_FIXUP_IMPL": "self", "RD_TEST_SELF_PEND": "2"},
-                                 {"RD_FIXUP_IMPL": "self", "RD_TEST_SELF_PEND": "2", "RD_TAIL_IMPL": "legacy"}])
-def test_self_fix_forms_agree_with_the_fixtures(dsp, batchmod, golden_streams, monkeypatch, env):
-    """RD_FIXUP_IMPL=self: a wave of the demod kernel re-evaluates the groups it flagged itself (rd_mf_selffix: k_fixup's
-    exact arithmetic, dsp.py:71-98 in float64 on integer data) and no k_fixup is launched; the search kernel clears
-    the next run's counters.  RD_TEST_SELF_PEND=2 lets a wave keep two entries only, so that most of them overflow
-    into the global list and the host runs k_fixup after the run, then search and slice again (ordered and unordered
-    tail).  Bits and packets of every form = the fixtures, twice in a row (the default form, k_fixup, is what every
-    other test runs)."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    seeds = list(range(12))
-    raw = synth.synth_streams(seeds)
-    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
-    for _ in range(2):
-        res = bd.demodulate(raw)
-        for i, seed in enumerate(seeds):
-            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
-            assert sha(bd.bits(i)) == golden_streams[str(seed)]["bits_sha256"], (env, seed)
-    assert bd.counters()["fixup_runs"] >= len(seeds)   # at least the first run of every stream
-    forms = bd.last_run_forms()
-    assert forms["self_fix"] and forms["second_pass"] == ("RD_TEST_SELF_PEND" in env)
-
-
-@pytest.mark.gpu
-def test_fused_search_equals_the_fixtures_and_the_c_oracle(dsp, batchmod, golden_streams, monkeypatch):
-    """RD_SEARCH_IMPL=fused: the demod kernel does the preamble test of dsp.py:171-188 itself (rd_mf_search_tile) and
-    k_search_rem evaluates what it leaves out - the windows around every word on the fix-up list and the seven words
-    in front of every chunk start.  (1) the 64 fixture streams; (2) bursts swept across a chunk start in steps of 12
-    samples (tile 16 of a stream = sample 32768: a chunk starts there whatever the chunk length, and its first word is
-    always on the fix-up list), so that matches fall into the boundary pass, into the window of a listed word, and
-    into both - against the C oracle: call, index, bytes, order."""
-    from oracle import c_oracle as CO
-    for k in ("RD_FIXUP_IMPL", "RD_TAIL_IMPL", "RD_SLICE_IMPL"):   # (forms that exclude this one, should the suite run under them)
-        monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("RD_SEARCH_IMPL", "fused")
-    seeds = list(range(64))
-    raw = synth.synth_streams(seeds)
-    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(seeds), synth.BLOCKS_PER_STREAM)
-    for _ in range(2):
-        res = bd.demodulate(raw)
-        for i, seed in enumerate(seeds):
-            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
-        assert bd.last_run_forms() == {"ordered_tail": True, "self_fix": False, "fused_search": True, "second_pass": False, "one_launch_tail": False}
-    bd.close()
-    starts = [32768 - 448 - 300 + 12 * k for k in range(34)] + [8 * 8192 - 448 - 120 + 12 * k for k in range(14)]
-    swept = np.stack([synth.synth_stream(100 + k, start=st) for k, st in enumerate(starts)])
-    ocfg = CO.make_cfg(19200, 14, 16, 80, "1100101110001001", 8192)
-    want, _ = CO.demod_batch(swept, ocfg, threads=4, cap_per_stream=512)
-    bd = batchmod.BatchDemodulator(prod_cfg(dsp), len(starts), synth.BLOCKS_PER_STREAM)
-    res = bd.demodulate(swept)
-    assert bd.last_run_forms()["fused_search"] and not bd.last_run_forms()["second_pass"]
-    near = 0
-    for i in range(len(starts)):
-        got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
-        exp = [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
-        assert got == exp, (i, starts[i], len(got), len(exp))
-        near += sum(1 for p in want[i] if any(abs((p.call * 8192 + p.index - 8192) - edge) < 260 for edge in (32768, 65536)))
-    assert near >= 40   # the sweep did put matches next to the chunk starts (position = call * B + index - (L - B))
 
 
 @pytest.mark.gpu
@@ -1163,13 +1101,13 @@ def test_pipelined_handle_rerun_on_another_stream(dsp, batchmod, golden_streams)
 @pytest.mark.gpu
 def test_one_launch_tail_is_the_default_and_equals_the_other_forms(dsp, batchmod, golden_streams, monkeypatch):
     """Everything behind the demod kernel - exact bits for the listed groups, Demodulator._search and ._slice
-    (dsp.py:171-246: order, dedupe, RSSI / SNR) - runs as ONE launch by default; RD_TAIL_IMPL=ordered / legacy select
-    round 3's four launches and the unordered kernels + host ordering.  All three: the fixtures' packets, the same
-    records field for field, the same bits.  13 streams: three whole groups of four and a partial one."""
+    (dsp.py:171-246: order, dedupe, RSSI / SNR) - runs as ONE launch by default; RD_TAIL_IMPL=legacy selects the
+    separate kernels + host ordering.  Both: the fixtures' packets, the same records field for field, the same bits.
+    13 streams: three whole groups of four and a partial one."""
     seeds = list(range(13))
     raw = synth.synth_streams(seeds)
     out = {}
-    for impl in (None, "ordered", "legacy"):
+    for impl in (None, "legacy"):
         if impl is None:
             monkeypatch.delenv("RD_TAIL_IMPL", raising=False)
         else:
@@ -1180,13 +1118,13 @@ def test_one_launch_tail_is_the_default_and_equals_the_other_forms(dsp, batchmod
             bd.run()
             rec = bd.results().copy()
         forms = bd.last_run_forms()
-        assert forms["one_launch_tail"] == (impl is None) and forms["ordered_tail"] == (impl != "legacy") and not forms["second_pass"]
+        assert forms["one_launch_tail"] == (impl is None) and forms["ordered_tail"] == (impl is None) and not forms["second_pass"]
         res = bd.packets()
         for i, seed in enumerate(seeds):
             assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
             assert sha(bd.bits(i)) == golden_streams[str(seed)]["bits_sha256"]
         out[impl] = (rec, bd.counters())
-    for impl in ("ordered", "legacy"):
+    for impl in ("legacy",):
         a, b = out[None][0], out[impl][0]
         assert len(a) == len(b)
         for f in ("stream", "call", "index", "nbytes", "data"):
@@ -1253,3 +1191,56 @@ def test_one_launch_tail_overflows_fall_back(dsp, batchmod, golden_streams, monk
             assert np.array_equal(bd.bits(i), wbits[i]), i
             got = [(c, p.index, bytes(p.data).hex()) for c, ps in enumerate(res[i]) for p in ps]
             assert got == [(p.call, p.index, bytes(p.data).hex()) for p in want[i]]
+
+
+@pytest.mark.gpu
+def test_zero_copy_ring_input_equals_the_fixtures(dsp, golden_streams):
+    """SURVEY section 8f-4 literally: blocks that lie in a multiprocessing.shared_memory ring (rtldavis_amd.ring) are
+    demodulated where the producer wrote them - Demodulator.register_input pins and maps the segment, submit_from
+    launches on a slot - uint8 and complex128 blocks, two in flight, several times round a 4-slot ring: the fixtures'
+    packets (dsp.py:139-246), and the reference's size error for a wrong count."""
+    from rtldavis_amd.ring import BlockRing, KIND_C128
+    B = 8192
+    raw = synth.synth_stream(0)
+    want = dense_calls(golden_streams["0"]["calls"], synth.BLOCKS_PER_STREAM)
+    ring = BlockRing.create(n_slots=4, block_size=B)
+    try:
+        dem = dsp.Demodulator(prod_cfg(dsp))
+        dem.register_input(ring.data)
+        with pytest.raises(ValueError):
+            dem.submit_from(0, 2 * B - 2)
+        with pytest.raises(ValueError):
+            dem.submit_from(8, 2 * B)              # not 16-byte aligned
+        calls, inflight = [], 0
+        for b in range(synth.BLOCKS_PER_STREAM):
+            assert ring.put(raw[2 * B * b: 2 * B * (b + 1)], timeout=5.0)
+            slot, off, kind, count = ring.get(taken=inflight, timeout=5.0)
+            dem.submit_from(off, count, kind == KIND_C128)
+            inflight += 1
+            if inflight == 2:
+                calls.append(dem.fetch())
+                ring.release()
+                inflight -= 1
+        calls.append(dem.fetch())
+        ring.release()
+        assert_calls_equal(calls, want)
+        assert ring.backlog == (synth.BLOCKS_PER_STREAM, synth.BLOCKS_PER_STREAM)
+        # complex blocks through the same ring: the complex-input fixture (dsp.py:144-150)
+        g = load_json("complex_input.json")
+        rawc = np.fromfile(f"{GOLDEN}/burst_seed0_b20_22.u8", dtype=np.uint8)
+        x = (rawc[0::2].astype(np.float64) - 127.5) / 127.5 + 1j * (rawc[1::2].astype(np.float64) - 127.5) / 127.5
+        dem.reset()
+        ccalls = []
+        for b in range(x.size // B):
+            assert ring.put(x[B * b: B * (b + 1)], timeout=5.0)
+            slot, off, kind, count = ring.get(timeout=5.0)
+            assert kind == KIND_C128 and count == B
+            dem.submit_from(off, count, True)
+            ccalls.append(dem.fetch())
+            ring.release()
+        assert_calls_equal(ccalls, g["calls"])
+        dem.register_input(None)
+        with pytest.raises(RuntimeError):
+            dem.submit_from(0, 2 * B)              # nothing registered any more
+    finally:
+        ring.close()

@@ -1,4 +1,4 @@
-"""In-kernel stamps of the demod kernel (diagnostic library, RD_OPT_STAMP variants): where a wave's time goes.
+"""In-kernel stamps of the demod kernel (diagnostic library, RD_K1_STAMPS=1): where a wave's time goes.
 
 Per wave the kernel sums, in shader cycles (s_memtime), the loop-top wait for the tile (vmcnt), the stretch from
 there to the last load of the next tile issued (window read, word store, address arithmetic, LDS-DMA issue) and the
@@ -6,7 +6,7 @@ rest (the arithmetic); it also stamps s_memrealtime (100 MHz) at both ends, so t
 d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
 
 usage: k1_stamps.py NAME=ENV1=V1,ENV2=V2 ...   one subprocess per variant (the library reads its switches once)
-The stamp bit (RD_K1_OPT & 4) must be part of the variant.  A stamped build is ~10 % slower than the real kernel:
+RD_K1_STAMPS=1 must be part of the variant.  A stamped build is ~10 % slower than the real kernel:
 read the SHARES and the clock, not the length.
 """
 import json

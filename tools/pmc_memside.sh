@@ -2,7 +2,7 @@
 # Memory-side counters of the demod kernel and of its loads-only / loads+stores ablations (diagnostic library):
 # where do the 6 % of output bytes cost their time, and what does the load path look like from L1 / L2 / EA?
 # One rocprofv3 run per counter group (never together with a trace); python3 straight after `--`.
-#   usage: bash tools/pmc_memside.sh <outdir> [variants...]     variant = name:RD_K1_DEBUG:RD_K1_OPT
+#   usage: bash tools/pmc_memside.sh <outdir> [variants...]     variant = name:RD_K1_DEBUG:RD_K1_STAMPS
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=${1:-$ROOT/gpurun_out/pmc_memside}; shift
@@ -23,7 +23,7 @@ G[utcl1]="TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLAT
 G[sq]="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"
 for V in $VARS; do
   IFS=: read NAME DBG OPT <<< "$V"
-  export RD_K1_DEBUG=$DBG RD_K1_OPT=$OPT
+  export RD_K1_DEBUG=$DBG RD_K1_STAMPS=$OPT RD_TAIL_IMPL=legacy
   for K in ea_latency ea_stalls l2_hits l2_busy l1_latency utcl1 sq; do
     D=$OUT/${NAME}_$K
     rm -rf $D

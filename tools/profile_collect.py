@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-DEMOD_KERNEL_SYMBOL = "_Z12k_demod_mfmaILi0ELi1ELi10EE"   # k_demod_mfma<0, 1, RD_MF_PRODUCT_OPT>: the default variant
+DEMOD_KERNEL_SYMBOL = "_Z12k_demod_mfmaILi0ELb0EE"   # k_demod_mfma<0, false>: the product kernel
 STAMP_FILE = os.path.join(ROOT, "rtldavis_amd", "librtldavis_hip.stamp")
 
 

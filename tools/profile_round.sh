@@ -5,7 +5,7 @@
 # Every rocprofv3 run is its own process with python3 straight after `--`; counters (--pmc) never share a
 # run with a trace; each step is time-limited and the script stops at the first failure.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 COMMIT=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -36,10 +36,9 @@ python3 $ROOT/tools/profile_collect.py traffic $OUT $COMMIT > $OUT/traffic.json
 cat $OUT/traffic.json | tee -a $OUT/progress.log
 
 step "5/9 ablations of the demod kernel (tools/k1_ab.py, diagnostic library: librtldavis_hip_diag.so)"
-# RD_AB_TIMING=1: demod kernel + whole run (the ordered tail stays on); RD_K1_OPT: 2 = halo carry, 8 = 8-output blocks
-# (10 = the product), 16 = in-tile search probe; RD_K1_DEBUG: 1 compute only, 2 loads + stores only, 6 loads only,
-# 7 no guard band, 4 / 5 (16-output kernel only) no MFMA / MFMA only
-RD_AB_TIMING=1 timeout -k 10 700 python3 $ROOT/tools/k1_ab.py --key all --rounds 2 product_b8=RD_K1_OPT=10 b16=RD_K1_OPT=2 b8_no_halo=RD_K1_OPT=8 b8_no_guard=RD_K1_DEBUG=7,RD_K1_OPT=10 b8_compute_only=RD_K1_DEBUG=1,RD_K1_OPT=10 loads_stores_only=RD_K1_DEBUG=2,RD_K1_OPT=10 loads_only=RD_K1_DEBUG=6,RD_K1_OPT=10 b16_no_mfma=RD_K1_DEBUG=4,RD_K1_OPT=0 b16_mfma_only=RD_K1_DEBUG=5,RD_K1_OPT=0 b8_search_probe=RD_K1_OPT=26 valu=RD_K1_IMPL=valu wgs3=RD_K1_WGS_PER_CU=3 chunk8=RD_K1_CHUNK=8 chunk28=RD_K1_CHUNK=28 legacy_tail=RD_TAIL_IMPL=legacy > $OUT/ablation.txt 2>&1
+# RD_AB_TIMING=1: demod kernel + whole run.  RD_K1_DEBUG (wrong results): 1 compute only, 2 loads + stores only, 6 loads only,
+# 7 no guard band; valu = the round-1 kernel; legacy_tail = the separate tail kernels + host ordering
+RD_AB_TIMING=1 timeout -k 10 700 python3 $ROOT/tools/k1_ab.py --key all --rounds 2 product no_guard=RD_K1_DEBUG=7 compute_only=RD_K1_DEBUG=1 loads_stores_only=RD_K1_DEBUG=2 loads_only=RD_K1_DEBUG=6 plain_stores=RD_K1_STFLAGS=1 valu=RD_K1_IMPL=valu wgs3=RD_K1_WGS_PER_CU=3 chunk8=RD_K1_CHUNK=8 chunk28=RD_K1_CHUNK=28 legacy_tail=RD_TAIL_IMPL=legacy > $OUT/ablation.txt 2>&1
 cat $OUT/ablation.txt | tee -a $OUT/progress.log
 
 step "6/9 wideband (channelizer) line and its kernel stats"

@@ -23,6 +23,37 @@ for rep in range(6):
 ts = np.array(ts[5:]) * 1e3
 print(f"demodulate(): median {np.median(ts):.3f} ms, p99 {np.percentile(ts, 99):.3f} ms, max {ts.max():.3f} ms over {ts.size} calls; "
       f"{1e3 / np.mean(ts):.0f} blocks/s = {1e3 / np.mean(ts) * B / 1e6:.1f} MS/s; {npk} packets")
+# the first state-mirror read after the first blocks (protocol.py:307-309 reads .discriminated for the first CRC-valid packet)
+t0 = time.perf_counter(); d = dem.discriminated; t1 = time.perf_counter()
+print(f"first .discriminated materialisation {1e3*(t1-t0):.3f} ms")
+# complex input (py:144-150): what pyrtlsdr's sdr.stream() yields (runners/rtlsdr.py:100-103); (k - 127.5) / 127.5 stands in
+# for pyrtlsdr's own scaling
+cblocks = [((b[0::2].astype(np.float64) - 127.5) / 127.5 + 1j * (b[1::2].astype(np.float64) - 127.5) / 127.5) for b in blocks]
+demc = dsp.Demodulator(cfg)
+tc, npc = [], 0
+for rep in range(6):
+    demc.reset()
+    for blk in cblocks:
+        t0 = time.perf_counter()
+        pk = demc.demodulate(blk)
+        tc.append(time.perf_counter() - t0)
+        npc += len(pk)
+tc = np.array(tc[5:]) * 1e3
+print(f"complex input, demodulate(): median {np.median(tc):.3f} ms, p99 {np.percentile(tc, 99):.3f} ms, max {tc.max():.3f} ms over {tc.size} calls; "
+      f"{1e3 / np.mean(tc):.0f} blocks/s; {npc} packets (form: {os.environ.get('RD_STREAM_IMPL', 'one launch per block')})")
+t0 = time.perf_counter()
+nq = 0
+for rep in range(10):
+    demc.reset()
+    demc.submit(cblocks[0])
+    for blk in cblocks[1:]:
+        demc.submit(blk)
+        nq += len(demc.fetch())
+    nq += len(demc.fetch())
+dt = time.perf_counter() - t0
+print(f"complex input, submit()/fetch(), two blocks in flight: {10 * 33 / dt:.0f} blocks/s ({1e3 * dt / 330:.3f} ms per block); {nq} packets")
+t0 = time.perf_counter(); d = demc.discriminated; t1 = time.perf_counter()
+print(f"complex input, first .discriminated materialisation {1e3*(t1-t0):.3f} ms")
 # pipelined: two blocks in flight
 npk2 = 0
 t0 = time.perf_counter()
