@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--wideband", action="store_true",
                     help="BASELINE configs[2] instead of the headline workload: 51 hop channels out of one "
                          "synthetic 26.88 MS/s capture (channelizer + demodulator), N = 1 only")
+    ap.add_argument("--host-fed", action="store_true",
+                    help="also measure the path fed from (pinned) host memory: upload(i+1) on a copy stream beside run(i). "
+                         "Reported as a separate `host_fed` object - PCIe-bound by construction, never `value`")
     ap.add_argument("--dist-backend", choices=("auto", "nccl", "gloo"), default="auto",
                     help="N > 1: backend of the barrier / max-over-ranks time (no data-path collective exists). auto = nccl (RCCL), "
                          "falling back to gloo in the same process when its initialisation fails")
@@ -364,6 +367,9 @@ def main():
         for x in bds:
             x.set_pipelined(True)
     in_bytes = host.nbytes
+    host_pinned = None
+    if args.host_fed:   # the same bytes in pinned memory, for the overlapped uploads measured after the timed region
+        host_pinned = torch.from_numpy(host).pin_memory()
     del host
 
     # --two-streams gives each resident batch its own HIP stream; measured: no gain, the demod
@@ -460,6 +466,41 @@ def main():
         sustained = {"seconds": round(dt_s, 2), "steps": k, "value": round(n_streams * n_samples * k / dt_s / 1e6, 1),
                      "unit": "MS/s", "ms_per_step": round(1e3 * dt_s / k, 4), "kernel_ms": round(float(dm2), 4),
                      "roofline_frac": round(n_streams * n_samples * 2 / (dm2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- host-fed leg (never `value`): every step's input crosses the bus.  upload(i + 1) is issued on a copy stream
+    # while run(i) computes (rd_batch_upload_async: the run waits for its upload on the device, the upload for the
+    # previous run of its handle); the link decides - 2 bytes per sample over PCIe against 0.55 ms of kernels.
+    host_fed = None
+    if host_pinned is not None and world == 1:
+        hp = host_pinned.numpy().reshape(-1)
+        cs = torch.cuda.Stream()
+        for x in bds:
+            x.set_timing(0)
+        sync_all()
+        # the link by itself: plain pinned-memory uploads of the same buffer
+        t1 = time.perf_counter()
+        for _ in range(4):
+            bds[0].upload_async(hp, cs.cuda_stream)
+        torch.cuda.synchronize()
+        link_s = (time.perf_counter() - t1) / 4
+        kf = 12
+        t1 = time.perf_counter()
+        bds[0].upload_async(hp, cs.cuda_stream)
+        for i in range(kf):
+            if i + 1 < kf:
+                bds[(i + 1) % R].upload_async(hp, cs.cuda_stream)   # beside the run below
+            bds[i % R].run(streams[i % R])
+            frecs = bds[i % R].results()
+        torch.cuda.synchronize()
+        fed_s = (time.perf_counter() - t1) / kf
+        host_fed = {"value": round(n_streams * n_samples / fed_s / 1e6, 1), "unit": "MS/s", "steps": kf,
+                    "ms_per_step": round(1e3 * fed_s, 3), "h2d_GBps": round(in_bytes / link_s / 1e9, 2),
+                    "frac_of_link": round(link_s / fed_s, 4), "packets_per_step": int(len(frecs)),
+                    "note": "inputs in pinned host memory, upload(i+1) on a copy stream beside run(i): PCIe-bound by "
+                            "construction (2 B per sample over the link); link = the same uploads alone"}
+        recs, bd = bds[(kf - 1) % R].results(), bds[(kf - 1) % R]   # (what the verification below reads)
+        for x in bds:
+            x.set_timing(timing_level)
 
     # ---- verification outside the timed region: packets and bit hashes against the fixtures
     verified = None
@@ -585,6 +626,8 @@ def main():
             out["roofline"]["traffic_source"] = traffic_source
         if sustained:
             out["sustained"] = sustained
+        if host_fed is not None:
+            out["host_fed"] = host_fed
         if per_gpu is not None:
             out["per_gpu"] = per_gpu
             out["dist_backend"] = dist_backend + (f" ({dist_note})" if dist_note else "")

@@ -183,6 +183,11 @@ void rd_batch_destroy(rd_batch *b);
 int rd_batch_input_ptr(rd_batch *b, void **dev_ptr, size_t *nbytes);
 /* Host -> device copy of the whole input (PCIe; not part of the timed region of bench.py). */
 int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbytes);
+/* The same copy issued on `hip_stream` (hipStream_t, a copy stream of the caller's) without waiting: the handle's next
+ * rd_batch_run waits for it on the device, so the upload of one resident batch overlaps the kernels of another
+ * (host-fed pipelines: SURVEY section 7 "PCIe vs HBM").  iq_host: pinned memory, untouched until that run's results
+ * have been fetched.  The copy queues behind the handle's previous run (which still reads the input). */
+int rd_batch_upload_async(rd_batch *b, const uint8_t *iq_host, size_t nbytes, void *hip_stream);
 /* Run the whole path on the resident input.  hip_stream: a hipStream_t (NULL = default
  * stream).  Asynchronous; rd_batch_results synchronises. */
 int rd_batch_run(rd_batch *b, void *hip_stream);

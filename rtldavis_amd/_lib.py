@@ -74,6 +74,7 @@ SIGNATURES = {
     "rd_batch_destroy": (None, [_P]),
     "rd_batch_input_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "rd_batch_upload": (C.c_int, [_P, _P, C.c_size_t]),
+    "rd_batch_upload_async": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "rd_batch_run": (C.c_int, [_P, _P]),
     "rd_batch_results": (C.c_int, [_P, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),
     "rd_batch_copy_bits": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),

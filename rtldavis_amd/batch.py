@@ -63,6 +63,14 @@ class BatchDemodulator:
             raise ValueError("Incompatible array sizes")
         _lib.check(_lib.lib().rd_batch_upload(self._b, a.ctypes.data, a.size))
 
+    def upload_async(self, iq: np.ndarray, hip_stream: int) -> None:
+        """``upload`` issued on a copy stream without waiting (rd_batch_upload_async): the next ``run()`` waits for it
+        on the device.  ``iq`` must be contiguous uint8 in PINNED memory and stay untouched until that run's results
+        have been fetched."""
+        if iq.dtype != np.uint8 or not iq.flags["C_CONTIGUOUS"] or iq.size != self.n_streams * 2 * self.n_samples:
+            raise ValueError("Incompatible array sizes")
+        _lib.check(_lib.lib().rd_batch_upload_async(self._b, iq.ctypes.data, iq.size, C.c_void_p(hip_stream or None)))
+
     # ---- run ------------------------------------------------------------------------------
     def run(self, hip_stream: int = 0) -> None:
         """Launch the whole path (asynchronous) on a hipStream_t given as an integer handle."""

@@ -174,6 +174,8 @@ struct rd_batch {
     hipEvent_t done = nullptr;    // recorded after the run's readback copies: results wait on it,
                                   // not on the stream, so another batch may already be queued behind
     hipEvent_t kdone = nullptr;   // recorded after the run's last kernel
+    hipEvent_t uploaded = nullptr;  // recorded behind an rd_batch_upload_async copy: the next run's kernels wait for it
+    bool upload_pending = false;
     hipStream_t copy_stream = nullptr;  // readback runs here, beside the next batch's kernels
     uint32_t h_cnt[RD_CNT_SLOTS] = {};
     uint32_t *h_cnt_pin = nullptr;   // pinned: counters of the run in flight
@@ -324,6 +326,7 @@ static int batch_alloc(rd_batch *b) {
     HIPCHK(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&b->kdone, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&b->kfirst, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
     b->dev_ready = true;
     return RD_OK;
@@ -348,6 +351,7 @@ extern "C" void rd_batch_destroy(rd_batch *b) {
         if (b->done) hipEventDestroy(b->done);
         if (b->kdone) hipEventDestroy(b->kdone);
         if (b->kfirst) hipEventDestroy(b->kfirst);
+        if (b->uploaded) hipEventDestroy(b->uploaded);
         if (b->copy_stream) hipStreamDestroy(b->copy_stream);
         for (auto &e : b->evs) if (e) hipEventDestroy(e);
     }
@@ -380,6 +384,29 @@ extern "C" int rd_batch_upload(rd_batch *b, const uint8_t *iq_host, size_t nbyte
     }
     HIPCHK(hipMemcpy(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice));
     if (!b->ft_sticky) b->tail_off = false;  // a new input: the one-launch tail gets its chance again
+    return RD_OK;
+}
+
+// Host-fed batches without the serial upload (SURVEY section 7 "PCIe vs HBM"): the copy goes to `hip_stream` (a copy
+// stream of the caller's) and returns at once; the handle's next rd_batch_run waits for it ON THE DEVICE, so the upload
+// of one resident batch runs beside the kernels of another.  `iq_host` should be pinned (a pageable buffer makes the
+// runtime stage the copy and the call block) and must stay untouched until that run has been launched and the copy
+// has completed (rd_batch_results of that run is late enough).  The copy itself waits for the handle's previous run.
+extern "C" int rd_batch_upload_async(rd_batch *b, const uint8_t *iq_host, size_t nbytes, void *hip_stream) {
+    if (!b || !iq_host) return fail(RD_ERR_ARG, "null argument");
+    int rc = batch_alloc(b);
+    if (rc) return rc;
+    if (nbytes != b->iq_bytes) return fail(RD_ERR_ARG, "Incompatible array sizes: got %zu bytes, expected %zu", nbytes, b->iq_bytes);
+    hipStream_t cs = (hipStream_t)hip_stream;
+    if (b->ran && !b->fetched) {  // the previous run still reads the input: the copy queues behind its completion
+        rc = batch_flush(b);
+        if (rc) return rc;
+        HIPCHK(hipStreamWaitEvent(cs, b->done, 0));
+    }
+    HIPCHK(hipMemcpyAsync(b->d_iq, iq_host, nbytes, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipEventRecord(b->uploaded, cs));
+    b->upload_pending = true;
+    if (!b->ft_sticky) b->tail_off = false;
     return RD_OK;
 }
 
@@ -509,6 +536,10 @@ extern "C" int rd_batch_run(rd_batch *b, void *hip_stream) {
         HIPCHK(hipStreamWaitEvent(st, b->done, 0));
     }
     b->stream = st;
+    if (b->upload_pending) {  // rd_batch_upload_async: the input is on its way
+        HIPCHK(hipStreamWaitEvent(st, b->uploaded, 0));
+        b->upload_pending = false;
+    }
     b->fetched = false;
     // counters: this run uses the set the previous run's fixup kernel cleared (both start at zero)
     b->cnt_set ^= 1;

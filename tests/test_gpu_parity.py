@@ -1244,3 +1244,35 @@ def test_zero_copy_ring_input_equals_the_fixtures(dsp, golden_streams):
             dem.submit_from(0, 2 * B)              # nothing registered any more
     finally:
         ring.close()
+
+
+@pytest.mark.gpu
+def test_upload_async_on_a_copy_stream(dsp, batchmod, golden_streams):
+    """rd_batch_upload_async: the copy goes to a copy stream and the handle's next run waits for it on the device; the
+    next upload of a handle queues behind its previous run.  Two handles alternate inputs - upload(i + 1) issued before
+    run(i)'s results are fetched - and every result equals the fixtures of the input that run was given."""
+    cs = _hip_stream()
+    sets = [list(range(0, 5)), list(range(5, 10)), list(range(10, 15))]
+    inputs = [np.ascontiguousarray(synth.synth_streams(s)) for s in sets]
+    bds = [batchmod.BatchDemodulator(prod_cfg(dsp), 5, synth.BLOCKS_PER_STREAM) for _ in range(2)]
+
+    def check(bd, seeds):
+        res = bd.packets()
+        for i, seed in enumerate(seeds):
+            assert_calls_equal(res[i], dense_calls(golden_streams[str(seed)]["calls"], synth.BLOCKS_PER_STREAM))
+
+    k = 7
+    bds[0].upload_async(inputs[0], cs)
+    for i in range(k):
+        if i + 1 < k:
+            bds[(i + 1) % 2].upload_async(inputs[(i + 1) % 3], cs)
+        bds[i % 2].run()
+        check(bds[i % 2], sets[i % 3])
+    # a second upload of the same handle without a fetch in between: it queues behind the run that still reads the input
+    bds[0].upload_async(inputs[1], cs)
+    bds[0].run()
+    bds[0].upload_async(inputs[2], cs)
+    bds[0].run()
+    check(bds[0], sets[2])
+    with pytest.raises(ValueError):
+        bds[0].upload_async(inputs[0][:, :-2].copy(), cs)
