@@ -46,13 +46,23 @@ timeout -k 10 300 python3 $ROOT/bench.py --wideband --steps 20 --warmup 3 > $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_wb -- python3 $ROOT/bench.py --wideband --steps 20 --warmup 3 > $OUT/bench_wideband_under_rocprof.json 2> $OUT/trace_wb.err
 python3 $ROOT/tools/profile_collect.py stats $OUT/trace_wb $OUT wideband_ | tee -a $OUT/progress.log
 
-step "7/9 streaming handle: synchronous and pipelined blocks per second"
+step "7/9 streaming handle: uint8 and complex input, the multi-launch form, the worker's queue hop against the ring"
 timeout -k 10 200 python3 $ROOT/tools/stream_latency.py > $OUT/stream_latency.txt 2>&1
+echo "== RD_STREAM_IMPL=legacy" >> $OUT/stream_latency.txt
+RD_STREAM_IMPL=legacy timeout -k 10 200 python3 $ROOT/tools/stream_latency.py 2>&1 | grep -E "complex|^demodulate" >> $OUT/stream_latency.txt
+echo "== worker: queue hop against the shared-memory ring (tools/worker_rate.py)" >> $OUT/stream_latency.txt
+timeout -k 10 300 python3 $ROOT/tools/worker_rate.py 2>&1 | grep -v "DSP worker\|stop signal" >> $OUT/stream_latency.txt
 cat $OUT/stream_latency.txt | tee -a $OUT/progress.log
 
 step "8/9 host cost of rd_batch_results, one-shot latency"
 timeout -k 10 200 python3 $ROOT/tools/results_cost.py > $OUT/results_cost.txt 2>&1
 cat $OUT/results_cost.txt | tee -a $OUT/progress.log
+
+step "8b/9 host-fed leg and the one-launch tail's phase stamps"
+timeout -k 10 300 python3 $ROOT/bench.py --no-cpu-baseline --live-traffic 0 --sustain 0 --host-fed > $OUT/host_fed.json 2> $OUT/host_fed.err
+tail -c 500 $OUT/host_fed.json | tee -a $OUT/progress.log
+RTLDAVIS_HIP_LIB=$ROOT/rtldavis_amd/librtldavis_hip_diag.so RD_FT_STAMPS=1 timeout -k 10 300 python3 $ROOT/tools/tail_stamps.py > $OUT/tail_stamps.txt 2>&1
+cat $OUT/tail_stamps.txt | tee -a $OUT/progress.log
 
 step "9/9 N = 2 rehearsal on one GPU (code path only, not a measurement)"
 timeout -k 10 400 python3 $ROOT/bench.py --gpus 2 --steps 6 --warmup 2 --rehearse-shared-gpu --streams 1024 --sustain 0 > $OUT/rehearse_shared_gpu.txt 2>&1

@@ -17,4 +17,4 @@ one = []
 for _ in range(50):
     t = time.perf_counter(); bd.run(); r = bd.results(); one.append(time.perf_counter() - t)
 print("tail=%s: results() on a finished run: median %.3f ms min %.3f ms, %d records; one-shot run()+results(): median %.3f ms min %.3f ms"
-      % (os.environ.get("RD_TAIL_IMPL", "ordered"), 1e3 * sorted(ts)[10], 1e3 * min(ts), len(r), 1e3 * sorted(one)[25], 1e3 * min(one)))
+      % (os.environ.get("RD_TAIL_IMPL", "k_tail (one launch)"), 1e3 * sorted(ts)[10], 1e3 * min(ts), len(r), 1e3 * sorted(one)[25], 1e3 * min(one)))
