@@ -1173,6 +1173,9 @@ __global__ __launch_bounds__(256) void k_rssi_u8(rd_layout lay, rd_devcfg cfg, c
 // overflowed raises RD_CNT_OVF bits (1, 2, 8; 16 = the spin limit): the host falls back to the separate kernels.
 // ------------------------------------------------------------------------------------------
 #define RD_FT_WG 256
+#ifndef RD_FT_DEPTH
+#define RD_FT_DEPTH 5   /* register buffers of the search phase (units in flight + 1) */
+#endif
 struct rd_ft_args {
     rd_layout lay;
     rd_devcfg cfg;
@@ -1391,30 +1394,42 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
                 }
             }
         };
-        uint32_t ra[NW], rb[NW], rc[NW];
-        // a wave's units: wave, wave + G, ...; (g, rem) of the unit to fetch next and of the unit to test next
+        // a wave's units: wave, wave + G, ...; (g, rem) of the unit to fetch next and of the unit to test next.  RD_FT_DEPTH
+        // register buffers in rotation: the words of the DEPTH - 1 units behind the one being tested are in flight.  A
+        // fetch past the wave's last unit re-reads that unit (no branch around a load: the compiler's wait counts stay
+        // exact only in straight-line code).
+        constexpr int DEPTH = RD_FT_DEPTH;
+        uint32_t rb[DEPTH][NW];
         const int dq = G / wgps, dr = G % wgps;
         int fg = wave / wgps, fr = wave % wgps, fu = wave;
         int tg = fg, tr = fr;
         auto step = [&](int &gg, int &rr) { gg += dq; rr += dr; if (rr >= wgps) { rr -= wgps; gg++; } };
+        auto fetch_next = [&](uint32_t (&r)[NW]) {
 #ifdef RD_DIAG
-        auto fetch_next = [&](uint32_t (&r)[NW]) { if (fu < units && !(a.abl & 2)) fetch(fg, fr, r); fu += G; step(fg, fr); };
-        auto test_next = [&](const uint32_t (&r)[NW]) { if (!(a.abl & 1)) test(tg, tr, r); else if (r[0] == 0x12345678u) s_cnt[0] = 1; step(tg, tr); };
-#else
-        auto fetch_next = [&](uint32_t (&r)[NW]) { if (fu < units) fetch(fg, fr, r); fu += G; step(fg, fr); };
-        auto test_next = [&](const uint32_t (&r)[NW]) { test(tg, tr, r); step(tg, tr); };
+            if (a.abl & 2) return;
 #endif
-        fetch_next(ra);
-        fetch_next(rb);
-        for (int u = wave; u < units; u += 3 * G) {
-            fetch_next(rc);
-            test_next(ra);
-            if (u + G >= units) break;
-            fetch_next(ra);
-            test_next(rb);
-            if (u + 2 * G >= units) break;
-            fetch_next(rb);
-            test_next(rc);
+            fetch(fg, fr, r);
+            if (fu + G < units) { fu += G; step(fg, fr); }   // (scalar: past the last unit the position stays where it is)
+        };
+        auto test_next = [&](const uint32_t (&r)[NW]) {
+#ifdef RD_DIAG
+            if (a.abl & 1) { if (r[0] == 0x12345678u) s_cnt[0] = 1; step(tg, tr); return; }
+#endif
+            test(tg, tr, r);
+            step(tg, tr);
+        };
+        if (wave < units) {
+#pragma unroll
+            for (int j = 0; j < DEPTH - 1; j++) fetch_next(rb[j]);
+            for (int u = wave; u < units; u += DEPTH * G) {
+#pragma unroll
+                for (int j = 0; j < DEPTH; j++) {
+                    if (u + j * G < units) {   // wave-uniform
+                        fetch_next(rb[(j + DEPTH - 1) % DEPTH]);
+                        test_next(rb[j]);
+                    }
+                }
+            }
         }
     }
     if (wave == 0) RD_FT_STAMP(6);   // (wave 0's own end of the search: the barrier's wait is 2 - 6)
