@@ -1325,8 +1325,10 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
     if (wave == 0) RD_FT_STAMP(1);
 
     // ---- 1. preamble search over this workgroup's streams: a wave = 64 lanes x 128 positions of one stream ----
-    // Three register buffers in rotation: the words of the two units after the one being tested are in flight (with one
-    // unit's loads waited for at the top of every trip this phase took 41 us of memory latency for 25 us of vector issue).
+    // RD_FT_DEPTH register buffers in rotation: the words of the units behind the one being tested are in flight.  (With
+    // one unit's loads waited for at the top of every trip this phase took 41 us; with two or four units in flight 38: loads
+    // alone take 24.6 us = 5.6 TB/s of bits, the test alone 21.7, and together they add up rather than overlap - the memory
+    // path follows the clock the arithmetic pulls down.  profiles/r04_tail_stamps.txt)
     {
         constexpr int NW = ((RD_SEARCH_OUT + ((P_ - 1) * S_ + 31) / 32 + 1 + 3) / 4) * 4;
         const int gps = a.p_hi / (32 * RD_SEARCH_OUT) + 1;       // lane-groups per stream
