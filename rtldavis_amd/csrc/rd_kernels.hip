@@ -1263,6 +1263,11 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
         for (uint32_t i = tid; i < a.zero_words; i += RD_FT_WG) a.zero_next[i] = 0;
     if (tid < G) { s_cnt[tid] = 0; s_kept[tid] = 0; }
     if (tid == 0) s_ready = 0;
+    // The SIMD arbiter serves the oldest wave first: of the four workgroups that share a CU the first dispatched ran its
+    // search in 30 us, the last in 48, and every group behind it waited for its total.  Workgroups are dispatched in
+    // ascending order, a quarter of the grid per round: quarter q's waves raise and lower their priority in rotation
+    // (search unit k runs at priority (q + k) & 3), so that the four waves of a SIMD take turns at the front.
+    const int prio_q = (int)(((unsigned)grp * 4u) / (unsigned)n_groups);
     if (wave == 0) RD_FT_STAMP(0);
 
     // ---- 0. exact bits for the listed groups of this workgroup's streams (k_fixup's listed branch) ----
@@ -1404,7 +1409,7 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
         uint32_t rb[DEPTH][NW];
         const int dq = G / wgps, dr = G % wgps;
         int fg = wave / wgps, fr = wave % wgps, fu = wave;
-        int tg = fg, tr = fr;
+        int tg = fg, tr = fr, prio_k = 0;
         auto step = [&](int &gg, int &rr) { gg += dq; rr += dr; if (rr >= wgps) { rr -= wgps; gg++; } };
         auto fetch_next = [&](uint32_t (&r)[NW]) {
 #ifdef RD_DIAG
@@ -1417,6 +1422,12 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
 #ifdef RD_DIAG
             if (a.abl & 1) { if (r[0] == 0x12345678u) s_cnt[0] = 1; step(tg, tr); return; }
 #endif
+            switch ((prio_q + prio_k++) & 3) {   // (the operand of s_setprio is an immediate)
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
             test(tg, tr, r);
             step(tg, tr);
         };
@@ -1434,6 +1445,7 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (wave == 0) RD_FT_STAMP(6);   // (wave 0's own end of the search: the barrier's wait is 2 - 6)
     rd_barrier_lds();
     if (wave == 0) RD_FT_STAMP(2);
