@@ -628,7 +628,7 @@ static int batch_finish(rd_batch *b) {
             // guard list overflowed (degenerate input): re-evaluate every run exactly
             const rd_layout lay = batch_layout(b);
             rd_launch_fixup(lay, b->d_fix, b->fix_cap, batch_cnt(b), 1, nullptr, st);
-            // mark handled: neither this branch nor the self-fix one below may see the count again
+            // mark handled: this branch must not see the count again
             uint32_t cap = b->fix_cap;
             HIPCHK(hipMemcpyAsync(batch_cnt(b) + RD_CNT_FIX, &cap, sizeof cap, hipMemcpyHostToDevice, st));
             b->last_fix = (uint64_t)b->n_streams * b->bits_stride;
@@ -723,7 +723,7 @@ extern "C" int rd_batch_results(rd_batch *b, rd_packet *out, int cap, int *n) {
             memcpy(out, b->h_recs_pin, (size_t)nrec * sizeof(rd_packet));
         }
         if (dbg_host())
-            fprintf(stderr, "[rd] results (ordered tail): finish %.3f ms, D2H %u recs %.3f ms, copy %.3f ms\n", t1 - t0, nrec,
+            fprintf(stderr, "[rd] results (k_tail): finish %.3f ms, D2H %u recs %.3f ms, copy %.3f ms\n", t1 - t0, nrec,
                     t2 - t1, now_ms() - t2);
         return RD_OK;
     }

@@ -3,7 +3,7 @@
 // -fsanitize=address,undefined (SURVEY section 5's sanitizer stance; the GPU pool allows no sanitizer runs).
 //   rd_make_devcfg        PacketConfig's derived constants (py:101-125) and the limits the kernels rely on
 //   rd_order_and_dedupe   the per-call order and first-occurrence dedupe of Demodulator._slice (py:171-205)
-//   rd_ord_bucket_cap     per-stream bucket size of the ordered tail, from the stream's length
+//   rd_ord_bucket_cap     matches a stream's list in k_tail's LDS holds, from the stream's length
 //   rd_check_block_count  "Incompatible array sizes" (py:32-36, py:145-149)
 //   rd_waiter             the polling policy of every host wait: spin, then yield, then sleep, with a deadline
 // py = /root/reference/src/rtldavis/dsp.py
@@ -33,10 +33,10 @@ struct rd_order_scratch {  // kept per handle: no allocation per call once warm
 };
 void rd_order_and_dedupe(const rd_packet *recs, size_t n, int S, rd_order_scratch &sc);
 
-// Ordered tail: matches one stream's bucket must hold.  Noise gives one raw preamble match per 2^16 positions
+// k_tail: matches one stream's list must hold.  Noise gives one raw preamble match per 2^16 positions
 // (~4 per second of a Davis stream), a burst a handful around its true position; the
-// capacity is 4x the noise expectation plus 24 for bursts, rounded up to a multiple of 32 (one half-wave strip of
-// k_classify_ord), at least 32 and at most RD_BUCKET_MAX.
+// capacity is 4x the noise expectation plus 12 for bursts, rounded up to a multiple of 32, at least 32 and at
+// most RD_BUCKET_MAX.
 #define RD_BUCKET_MIN 32
 #define RD_BUCKET_MAX 512
 uint32_t rd_ord_bucket_cap(long n_samples);

@@ -79,8 +79,8 @@ bool rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
 // all != 0: re-evaluate every run exactly (used when the guard list overflowed or the
 // layout does not meet the fast kernel's alignment requirements).
 // zero_next (may be null): RD_CNT_TOTAL words (counters and work queues) to clear for the handle's next run.
-// zero_words: how many words at zero_next (the counter set, plus the per-stream match counters of the ordered tail
-// when the handle has them behind it)
+// zero_words: how many words at zero_next (the counter set, plus k_tail's per-group bucket counters when the handle
+// has them behind it)
 // expect (0: unknown): the list length of the handle's previous run - the grid is sized for it (+25 %) instead of
 // for the list's capacity (every lane loops with the grid's stride, so a short grid is only slower, never wrong)
 void rd_launch_fixup(const rd_layout &lay, const uint32_t *fix_list, uint32_t fix_cap, uint32_t *counters, int all,

@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_rssi_u8(rd_layout lay, rd_devcfg cfg, c
 
 // ------------------------------------------------------------------------------------------
 // k_tail (round 4): the WHOLE tail of a batch run in ONE launch (Davis shape).  Until round 3 a run's tail was four
-// launches - k_fixup, k_search, k_classify_ord, k_rssi_ord: 102 us of kernels that are each a launch, a ramp and a
+// launches - k_fixup, k_search and two slice / RSSI kernels with the order on the device: 102 us of kernels that are each a launch, a ramp and a
 // chain of dependent latencies, plus the gaps between dependent kernels of one stream.  Streams are independent
 // (dsp.py:131-135 holds all state per instance), so a workgroup that OWNS RD_FT_STREAMS consecutive streams can take
 // them through every stage without waiting for anybody:

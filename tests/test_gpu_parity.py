@@ -945,7 +945,7 @@ def test_pipelined_completion_returns_the_same_packets(dsp, batchmod, golden_str
 
 @pytest.mark.gpu
 def test_ordered_tail_falls_back_when_a_stream_overflows_its_bucket(dsp, batchmod, golden_streams, monkeypatch):
-    """RD_TEST_BUCKET_CAP=2: every stream has more than two matches, the ordered tail raises its overflow flag, and
+    """RD_TEST_BUCKET_CAP=2: every stream has more than two matches, the one-launch tail raises its overflow flag, and
     rd_batch_results re-runs the unordered kernels on the same bits - the fixtures' packets, twice in a row (the
     second run goes straight to the unordered path: no new upload in between), and again after a new upload."""
     monkeypatch.setenv("RD_TEST_BUCKET_CAP", "2")
