@@ -1134,20 +1134,21 @@ def test_one_launch_tail_is_the_default_and_equals_the_other_forms(dsp, batchmod
 
 
 @pytest.mark.gpu
-def test_long_streams_size_their_match_lists(dsp, batchmod):
+@pytest.mark.parametrize("ns,parts", [(6, 10), (3, 24)])
+def test_long_streams_size_their_match_lists(dsp, batchmod, ns, parts):
     """the per-stream match lists are sized from the stream's length (rd_host.h:
     rd_ord_bucket_cap): 330 blocks of noise with ten bursts (each stream = ten fixture-style streams back to back) hold
     ~45 raw preamble matches per stream - more than the 32 of round 3's buckets - and still take the one-launch
-    tail in its first pass.  Packets and bits against the C oracle (dsp.py:171-246)."""
+    tail in its first pass; 792 blocks: lists of 416 matches, 98 KiB of dynamic LDS per workgroup (above the 64 KiB a
+    kernel gets without asking).  Packets and bits against the C oracle (dsp.py:171-246)."""
     from oracle import c_oracle as CO
-    ns, parts = 6, 10
     raw = np.stack([np.concatenate([synth.synth_stream(100 + 17 * s + k) for k in range(parts)]) for s in range(ns)])
     nb = parts * synth.BLOCKS_PER_STREAM
     bd = batchmod.BatchDemodulator(prod_cfg(dsp), ns, nb)
     res = bd.demodulate(raw)
     forms = bd.last_run_forms()
     assert forms["one_launch_tail"] and forms["ordered_tail"] and not forms["second_pass"]
-    want, wbits = CO.demod_batch(raw, CO.make_cfg(), threads=4, want_bits=True)
+    want, wbits = CO.demod_batch(raw, CO.make_cfg(), threads=4, want_bits=True, cap_per_stream=4096)
     assert max(len(w) for w in want) > 32
     for i in range(ns):
         assert np.array_equal(bd.bits(i), wbits[i]), i
