@@ -542,9 +542,8 @@ def main():
                 "ms_per_step": round(1e3 * own_elapsed / args.steps, 4), "kernel_ms": round(dm_own, 4),
                 "roofline_frac": round(n_streams * n_samples * 2 / (dm_own * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "verified": own_verified}
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        per_gpu = sorted(gathered, key=lambda d: d["rank"])
+        from rtldavis_amd import shard
+        per_gpu = shard.gather_rank_lines(mine)
 
     # HBM traffic of the dominant kernel: measured with PMC counters in separate rocprofv3 runs
     # (tools/profile_round.sh) and committed under profiles/ together with a sha256 over the kernel's INSTRUCTIONS as

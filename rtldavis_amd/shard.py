@@ -53,3 +53,16 @@ def demodulate_sharded(n_streams: int, load_shard: Callable[[int, int], object],
     lo, hi = shard_range(n_streams, world, rank)
     local = demod_shard(load_shard(lo, hi)) if hi > lo else []
     return gather_records(local, lo, group)
+
+
+def gather_rank_lines(line: dict, group=None) -> List[dict]:
+    """Every rank's own measurement line (bench.py: rank, device, value, ms_per_step, kernel_ms, roofline_frac, verified)
+    on every rank, in rank order - BASELINE configs[4] asks for per-GPU MSamples/s next to the aggregate, and a straggler
+    GPU is invisible in a MAX(elapsed) alone.  Host-side object gather; no data-path collective."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [line]
+    bucket = [None] * dist.get_world_size(group)
+    dist.all_gather_object(bucket, line, group=group)
+    return sorted(bucket, key=lambda d: d["rank"])

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from rtldavis_amd import synth
-from rtldavis_amd.shard import demodulate_sharded, shard_range
+from rtldavis_amd.shard import demodulate_sharded, gather_rank_lines, shard_range
 
 N_STREAMS = 5
 SEEDS = list(range(N_STREAMS))
@@ -36,6 +36,9 @@ def _worker(rank, world, port, q):
     lo, hi = shard_range(N_STREAMS, world, rank)
     out = demodulate_sharded(N_STREAMS, lambda a, b: synth.synth_streams(SEEDS[a:b], n_samples=6 * 8192),
                              _oracle_records)
+    # bench.py's per_gpu lines: every rank's own figures on every rank, in rank order
+    lines = gather_rank_lines({"rank": rank, "value": 100.0 + rank, "verified": True})
+    assert [d["rank"] for d in lines] == list(range(world)) and [d["value"] for d in lines] == [100.0 + r for r in range(world)]
     if rank == 0:
         q.put(out)
     else:
