@@ -1494,6 +1494,7 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
         e[0] = uint4{(ok0 ? 1u : 0u) | (ok1 ? 2u : 0u), (uint32_t)b0, (ph0 << 24) | (uint32_t)q0, (ph1 << 24) | (uint32_t)q1};
         e[1] = uint4{dw[0], dw[1], dw[2], 0u};
     }
+    if (wave == 0) RD_FT_STAMP(7);   // (wave 0: its stream's entries are in LDS)
     // (a wave reads what the same wave wrote: LDS operations of a wave complete in order, no barrier needed)
     // pass 1: a task is a duplicate when a task of the same call with the same bytes precedes it (py:203-205)
     for (uint32_t j = lane; j < ((count + 63) & ~63u); j += 64) {
@@ -1503,15 +1504,28 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
         const int b0 = (int)me.y, b1 = b0 - 1;
         const uint32_t k0 = me.z, k1 = me.w;
         bool dup0 = false, dup1 = false;
-        for (uint32_t i = 0; i < count; i++) {  // broadcast reads
-            const uint4 x = *(const uint4 *)(tg + 8 * i), d = *(const uint4 *)(tg + 8 * i + 4);
-            const int ob0 = (int)x.y;
-            const bool lower = i < j;  // equal keys = the same position twice: the lower slot counts as the earlier one
-            if (d.x == md.x && d.y == md.y && d.z == md.z) {
-                if ((x.x & 1u) && ob0 == b0 && (x.z < k0 || (x.z == k0 && lower))) dup0 = true;
-                if ((x.x & 2u) && ob0 - 1 == b0 && (x.w < k0 || (x.w == k0 && lower))) dup0 = true;
-                if ((x.x & 1u) && ob0 == b1 && (x.z < k1 || (x.z == k1 && lower))) dup1 = true;
-                if ((x.x & 2u) && ob0 - 1 == b1 && (x.w < k1 || (x.w == k1 && lower))) dup1 = true;
+        // four entries per trip, all eight broadcast reads issued before the first is used (a trip per entry waits for
+        // the LDS once per entry); the slots of a trip past the stream's count are read (they exist) and ignored
+        for (uint32_t i0 = 0; i0 < count; i0 += 4) {
+            uint4 xa[4], da[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = (i0 + u) < a.bcap ? i0 + u : i0;
+                xa[u] = *(const uint4 *)(tg + 8 * i);
+                da[u] = *(const uint4 *)(tg + 8 * i + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + u;
+                const uint4 x = xa[u], d = da[u];
+                const int ob0 = (int)x.y;
+                const bool lower = i < j;  // equal keys = the same position twice: the lower slot counts as the earlier one
+                if (i < count && d.x == md.x && d.y == md.y && d.z == md.z) {
+                    if ((x.x & 1u) && ob0 == b0 && (x.z < k0 || (x.z == k0 && lower))) dup0 = true;
+                    if ((x.x & 2u) && ob0 - 1 == b0 && (x.w < k0 || (x.w == k0 && lower))) dup0 = true;
+                    if ((x.x & 1u) && ob0 == b1 && (x.z < k1 || (x.z == k1 && lower))) dup1 = true;
+                    if ((x.x & 2u) && ob0 - 1 == b1 && (x.w < k1 || (x.w == k1 && lower))) dup1 = true;
+                }
             }
         }
         if (live) tg[8 * j + 7] = (((me.x & 1u) && !dup0) ? 1u : 0u) | (((me.x & 2u) && !dup1) ? 2u : 0u);
@@ -1525,13 +1539,24 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
         const int b0 = (int)me.y, b1 = b0 - 1;
         const uint32_t k0 = me.z, k1 = me.w;
         uint32_t r0 = 0, r1 = 0;
-        for (uint32_t i = 0; i < count; i++) {
-            const uint4 x = *(const uint4 *)(tg + 8 * i);
-            const uint32_t xk = tg[8 * i + 7] & 3u;
-            const int ob0 = (int)x.y;
-            auto before = [](int ca, uint32_t ka, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka < kb); };
-            if (xk & 1u) { r0 += before(ob0, x.z, b0, k0) ? 1u : 0u; r1 += before(ob0, x.z, b1, k1) ? 1u : 0u; }
-            if (xk & 2u) { r0 += before(ob0 - 1, x.w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, x.w, b1, k1) ? 1u : 0u; }
+        for (uint32_t i0 = 0; i0 < count; i0 += 4) {
+            uint4 xa[4];
+            uint32_t ka[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = (i0 + u) < a.bcap ? i0 + u : i0;
+                xa[u] = *(const uint4 *)(tg + 8 * i);
+                ka[u] = tg[8 * i + 7];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint4 x = xa[u];
+                const uint32_t xk = (i0 + u) < count ? ka[u] & 3u : 0u;
+                const int ob0 = (int)x.y;
+                auto before = [](int ca, uint32_t ka_, int cb, uint32_t kb) { return ca < cb || (ca == cb && ka_ < kb); };
+                if (xk & 1u) { r0 += before(ob0, x.z, b0, k0) ? 1u : 0u; r1 += before(ob0, x.z, b1, k1) ? 1u : 0u; }
+                if (xk & 2u) { r0 += before(ob0 - 1, x.w, b0, k0) ? 1u : 0u; r1 += before(ob0 - 1, x.w, b1, k1) ? 1u : 0u; }
+            }
         }
         kept_here += (uint32_t)__popcll(__ballot((mk & 1u) != 0)) + (uint32_t)__popcll(__ballot((mk & 2u) != 0));
         if (live) tg[8 * j + 7] = mk | (r0 << 2) | (r1 << 17);   // (ranks < 2 bcap <= 2^15)
@@ -1558,10 +1583,10 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
     // of this kernel had both and took 165 us instead of 60.  Nothing else travels between workgroups.
     const uint32_t tag = (a.seq & 0xFFFu) << 20;
     if (tid == 0) {
-        __hip_atomic_store(&a.gstate[grp], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.gstate[n_groups + grp], tag | (mtotal < 0xFFFFFu ? mtotal : 0xFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.gstate[2 * n_groups + grp], tag | (n_fix_raw < 0xFFFFFu ? n_fix_raw : 0xFFFFFu), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.gstate[grp], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the word the others wait for: last)
         if (n_fix_raw > a.fix_bcap) atomicOr(&a.counters[RD_CNT_OVF], 8u);
     }
     rd_barrier_lds();
@@ -1600,8 +1625,27 @@ __global__ __launch_bounds__(RD_FT_WG, 4) void k_tail(rd_ft_args a) {
         for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
         if (lane == 0) __hip_atomic_store(&s_ready, sum + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (grp == n_groups - 1) {  // the last group leaves the run's totals for the host
+            // (its prefix has seen every other group's first word, and a group stores its other two words BEFORE that one:
+            // they are there, as a rule - all loads of a round go out before the first is looked at, a word that is not
+            // there yet is polled.  A dependent load per word made this group the last to finish by 8 us)
             uint32_t mt = 0, ft = 0;
-            for (int i = lane; i < n_groups; i += 64) { mt += tagged(&a.gstate[n_groups + i]); ft += tagged(&a.gstate[2 * n_groups + i]); }
+            for (int i0 = 0; i0 < n_groups; i0 += 512) {
+                uint32_t vm[8], vf[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = i0 + lane + 64 * k;
+                    vm[k] = i < n_groups ? __hip_atomic_load(&a.gstate[n_groups + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                    vf[k] = i < n_groups ? __hip_atomic_load(&a.gstate[2 * n_groups + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = i0 + lane + 64 * k;
+                    if ((vm[k] & 0xFFF00000u) != tag) vm[k] = tagged(&a.gstate[n_groups + i]);
+                    if ((vf[k] & 0xFFF00000u) != tag) vf[k] = tagged(&a.gstate[2 * n_groups + i]);
+                    mt += vm[k] & 0xFFFFFu;
+                    ft += vf[k] & 0xFFFFFu;
+                }
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 mt += (uint32_t)__shfl_xor((int)mt, o, 64);

@@ -42,6 +42,7 @@ col("start after the first group's", a[:, 0])
 col("0 fix-up (to barrier)", a[:, 1] - a[:, 0])
 col("1 search, wave 0 alone", a[:, 6] - a[:, 1])
 col("1 search (to barrier)", a[:, 2] - a[:, 1])
+col("2 slice: words loaded, entries made", a[:, 7] - a[:, 2])
 col("2 slice + publish (to barrier)", a[:, 3] - a[:, 2])
 col("3 prefix known (wave 3) after 3", a[:, 4] - a[:, 3])
 col("3 rssi + records (wave 0) after 3", np.maximum(a[:, 5] - a[:, 3], 0))
@@ -51,3 +52,8 @@ sr = a[:, 6] - a[:, 1]
 print("  search (wave 0) by group % 8:", " ".join(f"{sr[k::8].mean():.1f}" for k in range(8)))
 print("  search (wave 0) by eighth of the grid:", " ".join(f"{c.mean():.1f}" for c in np.array_split(sr, 8)))
 print("  search (wave 0) by group % 32 // 8 (SE?):", " ".join(f"{sr[(np.arange(sr.size) % 32) // 8 == k].mean():.1f}" for k in range(4)))
+end = np.maximum(a[:, 5], a[:, 4])
+print("  end by eighth of the grid:", " ".join(f"{c.mean():.1f}" for c in np.array_split(end, 8)), "| max per eighth:", " ".join(f"{c.max():.1f}" for c in np.array_split(end, 8)))
+late = np.argsort(-end)[:10]
+for g in late:
+    print(f"  late group {g}: start {a[g,0]:.1f} fix {a[g,1]-a[g,0]:.1f} search {a[g,2]-a[g,1]:.1f} slice {a[g,3]-a[g,2]:.1f} prefix +{a[g,4]-a[g,3]:.1f} records +{a[g,5]-a[g,3]:.1f} end {end[g]:.1f}")
