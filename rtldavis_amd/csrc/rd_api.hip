@@ -925,6 +925,7 @@ struct rd_demod {
     // [hdr 16][prev B][cur B] complex128
     uint8_t *d_ring = nullptr;
     double *d_cring = nullptr;
+    uint32_t *d_sync = nullptr;   // k_stream_block_cplx's arrival counter (zero between launches)
     uint32_t *d_blockbits = nullptr, *d_win[2] = {nullptr, nullptr}, *d_fix = nullptr, *d_cnt = nullptr;
     int cur_win = 0;
     rd_match *d_matches = nullptr;
@@ -1018,6 +1019,8 @@ static int demod_alloc(rd_demod *h) {
     if (NS == 1) {
         HIPCHK(hipMalloc(&h->d_cring, 2 * (16 + 2 * B) * sizeof(double)));
         HIPCHK(hipMemset(h->d_cring, 0, 2 * (16 + 2 * B) * sizeof(double)));
+        HIPCHK(hipMalloc(&h->d_sync, 64));
+        HIPCHK(hipMemset(h->d_sync, 0, 64));
     }
     HIPCHK(hipDeviceSynchronize());  // the memsets above ran on the null stream
     {
@@ -1052,7 +1055,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         if (h->st) hipStreamSynchronize(h->st);
         if (h->st_copy) hipStreamSynchronize(h->st_copy);
         if (h->ext_host) hipHostUnregister(h->ext_host);
-        hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_blockbits);
+        hipFree(h->d_ring); hipFree(h->d_cring); hipFree(h->d_sync); hipFree(h->d_blockbits);
         hipFree(h->d_win[0]); hipFree(h->d_win[1]); hipFree(h->d_fix); hipFree(h->d_cnt);
         hipFree(h->d_matches); hipFree(h->d_tmp);
         hipHostFree(h->h_tmp);
@@ -1131,6 +1134,7 @@ extern "C" int rd_reset(rd_demod *h) {
         const size_t L = (size_t)h->dc.L;
         for (int i = 0; i < 2; i++)
             HIPCHK(hipMemsetAsync(h->d_win[i], 0, (size_t)h->NS * ((L + 31) / 32) * 4, h->st));
+        if (h->d_sync) HIPCHK(hipMemsetAsync(h->d_sync, 0, 64, h->st));   // (a launch that never finished may have left a count)
         int rc = wait_stream(h->st, "reset()'s clears");
         if (rc) return rc;
     }
@@ -1226,6 +1230,7 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex, long e
         a.flag_host = sl.d_sb_map + NS;
         a.seq = ++h->seq;
         a.seen_before = h->seen;
+        a.sync = h->d_sync;
         if (rd_launch_stream_block_cplx(a, st)) {
             HIPCHK(hipGetLastError());
             h->cur_win = nw;

@@ -127,6 +127,7 @@ void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_w
 // The streaming handle's one-launch block (k_stream_block, rd_kernels.hip): everything of one demodulate() call - ring
 // roll, exact bits, window, search, slice + RSSI, results into mapped host memory - for NS streams in lock step.
 #define RD_SB_THREADS 1024
+#define RD_SBC_THREADS 256   // k_stream_block_cplx: a workgroup takes 8 x this many samples of the block
 struct rd_sb_args {
     rd_devcfg cfg;
     uint8_t *ring;            // the streams' raw rings: [hdr 32 B][previous block][newest block], ring_stride apart
@@ -139,6 +140,7 @@ struct rd_sb_args {
     uint32_t *flag_host;      // mapped: seq per stream, stored last
     uint32_t seq;
     long seen_before;         // blocks since reset
+    uint64_t *stamps;         // diagnostic library: phase stamps (else null)
 };
 // 1 when the kernel was launched, 0 when the configuration is not one it is built for
 int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st);
@@ -156,6 +158,8 @@ struct rd_sbc_args {
     uint32_t *cnt_host, *flag_host;
     uint32_t seq;
     long seen_before;
+    uint32_t *sync;           // device word, zero between launches: the workgroups count themselves in
+    uint64_t *stamps;         // diagnostic library: phase stamps (else null)
 };
 int rd_launch_stream_block_cplx(const rd_sbc_args &a, hipStream_t st);
 

@@ -2044,6 +2044,28 @@ __device__ __forceinline__ uint32_t rd_lds_bits32(const uint32_t *w, int nwords,
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(o & 31));
 }
 
+#ifdef RD_DIAG
+// diagnostic library: s_memrealtime stamps of the streaming blocks' phases (stream 0's workgroup), RD_SB_STAMPS=1
+#define RD_SB_STAMP(k) do { if (a.stamps && threadIdx.x == 0 && blockIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                                                                                 a.stamps[(k)] = t_; } } while (0)
+#else
+#define RD_SB_STAMP(k) do { } while (0)
+#endif
+#ifdef RD_DIAG
+static uint64_t *g_sb_stamps = nullptr;
+static uint64_t *rd_sb_stamp_buffer() {
+    if (!getenv("RD_SB_STAMPS")) return nullptr;
+    if (!g_sb_stamps && (hipMalloc(&g_sb_stamps, 64) != hipSuccess || hipMemset(g_sb_stamps, 0, 64) != hipSuccess)) g_sb_stamps = nullptr;
+    return g_sb_stamps;
+}
+// stamps of the last streaming one-launch block (diagnostic library): 8 uint64 (s_memrealtime, 100 MHz)
+extern "C" int rd_diag_read_sb_stamps(uint64_t *out) {
+    if (!g_sb_stamps || !out) return RD_ERR_STATE;
+    if (hipDeviceSynchronize() != hipSuccess) return RD_ERR_DEVICE;
+    return hipMemcpy(out, g_sb_stamps, 64, hipMemcpyDeviceToHost) == hipSuccess ? RD_OK : RD_ERR_DEVICE;
+}
+#endif
+
 template <int S_, int P_, uint64_t PRE_, int K_>
 __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sb_lds[];
@@ -2057,6 +2079,7 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
     uint8_t *ring = a.ring + (size_t)stream * a.ring_stride;     // [hdr 32 B][previous block][newest block]
     const uint8_t *in = a.in + (size_t)stream * 2 * (size_t)B;
     const bool have_hist = a.seen_before > 0;
+    RD_SB_STAMP(0);
     if (tid == 0) s_nm = 0;
     // ---- 0: the roll.  Every load first (two 16-byte pieces per thread cover 2 B <= 32 KiB), then a barrier, then the
     // stores: the old newest block is read whole before it is overwritten, the old previous block's tail before the old
@@ -2079,6 +2102,7 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
     uint32_t oldw = 0;
     if (tid < nbw) oldw = win_in[nbw + tid];
     __syncthreads();
+    RD_SB_STAMP(1);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int i = tid + RD_SB_THREADS * k;
@@ -2094,7 +2118,9 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
     if (have_hist && tid < 2) *(uint4 *)(ring + 16 * (size_t)tid) = ph;
     if (!have_hist && tid < 2) *(uint4 *)(s_iq + 16 * tid) = uint4{0, 0, 0, 0};
     if (tid < nbw) s_win[tid] = oldw;
-    __syncthreads();
+    rd_barrier_lds();   // (LDS only: the ring stores drain under the arithmetic - 2 us of waiting for their acknowledgement
+                        // otherwise; the barriers in front of the slice, which reads the ring, wait for them)
+    RD_SB_STAMP(2);
     // ---- 1: exact sign bits, one 8-sample group per thread (dsp.py:38-98 in exact integer arithmetic) ----
     const long vfrom = have_hist ? -16 : 0;  // (ten samples of history are all a group needs)
     for (int g = tid; g < B / 8; g += RD_SB_THREADS) {
@@ -2108,6 +2134,7 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
         ((uint8_t *)(s_win + nbw))[g] = (uint8_t)rd_exact_group_dw(dw, (long)t0, 8, vfrom);
     }
     __syncthreads();
+    RD_SB_STAMP(3);
     // ---- 2: the window goes out for the state mirrors (rd_copy_quantized) and the next call ----
     for (int i = tid; i < nwin; i += RD_SB_THREADS) win_out[i] = s_win[i];
     // ---- 3: search, one 32-position word per thread; positions 0 .. B ----
@@ -2127,6 +2154,7 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
         }
     }
     __syncthreads();
+    RD_SB_STAMP(4);
     const uint32_t nm = s_nm;
     // ---- 4: slice + RSSI / SNR, one wave per match (k_slice_rssi's logic for batch_mode = 0) ----
     rd_packet *recs = a.recs_host + (size_t)stream * (size_t)(B + 1);
@@ -2172,12 +2200,18 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block(rd_sb_args a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: records and count before the flag
         __hip_atomic_store(&a.flag_host[stream], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    RD_SB_STAMP(5);
 }
 
-int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st) {
-    const rd_devcfg &c = a.cfg;
+int rd_launch_stream_block(const rd_sb_args &a_in, int n_streams, hipStream_t st) {
+    const rd_devcfg &c = a_in.cfg;
     if (!(c.S == 14 && c.P == 16 && c.K == 80 && c.pre_mask == 0x91D3ull) || c.L != 2 * c.B || c.B % 32 || c.B < 2048 || c.B > 16384)
         return 0;
+    rd_sb_args a = a_in;
+    a.stamps = nullptr;
+#ifdef RD_DIAG
+    a.stamps = rd_sb_stamp_buffer();
+#endif
     const size_t lds = 32 + 2 * (size_t)c.B + (size_t)(2 * c.B / 32) * 4 + ((size_t)c.B + 1) * 4;
     hipLaunchKernelGGL((k_stream_block<14, 16, 0x91D3ull, 80>), dim3((unsigned)n_streams), dim3(RD_SB_THREADS), lds, st, a);
     return 1;
@@ -2188,90 +2222,184 @@ int rd_launch_stream_block(const rd_sb_args &a, int n_streams, hipStream_t st) {
 // feeds the live receiver (/root/reference/src/rtldavis/runners/rtlsdr.py:100-103).  Single stream; the raw ring holds
 // complex128 [hdr 16][previous block][newest block]; the new block comes from the slot's mapped host buffer as
 // complex128 (16 bytes per sample) or - a uint8 block on a handle that has seen complex input - as bytes through the
-// LUT (py:26,38-39).  Signs from a float64 sum in tap order, as k_cplx_bits (rd_f_f64): a thread keeps the 17 samples
-// its 8-sample group needs in registers.  Window, search, slice and the flag protocol are k_stream_block's; the RSSI /
-// SNR windows are rd_rssi_f64's.  block_size <= 8192 (eight 16-byte pieces per thread in the roll).
+// LUT (py:26,38-39).  The block is 128 KB over the link: ONE workgroup asked for it at 10.7 GB/s (12 of its 19 us;
+// a CU has only so many reads in flight), so block_size / (8 T) workgroups of T threads each take 8 T samples:
+//   0  every load of the piece at once: the new samples from pinned host memory, the old newest block from the ring
+//      (py:140,154: the roll); the 16 samples in front of the piece for the filter's history
+//   1  ring stores (they drain under the arithmetic) and the ROTATED samples (py:46-49) into LDS, sample i in 16-byte
+//      chunk i + i/8: a thread of step 2 reads the 17 consecutive samples of its 8-sample group, lanes 8 samples apart
+//      = chunk stride 9, no bank asked twice (the same loads from global memory touched 64 cache lines per instruction)
+//   2  signs from a float64 sum in tap order (rd_f_f64's), one 8-sample group per thread.  The sign of py:80-90's
+//      quotient is the sign of its numerator - the denominator is a sum of squares + 1e-10 - so no float64 divide
+//      (finite input; a NaN numerator has no sign to agree on)
+//   3  the piece's sign words into the window; then the workgroup counts itself in.  The LAST one to arrive goes on
+//      alone: window, search, slice, RSSI / SNR, records, flag (k_stream_block's steps 2 - 5)
+// What one workgroup writes and another reads in the same launch - the ring (the RSSI windows reach into other pieces
+// and the previous block) and the window's words - travels as relaxed agent-scope atomics (sc1: written through to,
+// read from the level all XCDs share), each store acknowledged (s_waitcnt vmcnt(0)) before the workgroup's increment of
+// the arrival counter; no release / acquire fence (an L2 write-back and invalidate at agent scope, see k_tail).  Nobody
+// waits for anybody: a workgroup that is not the last simply ends.  The ring's last 16 samples (next block's filter
+// history, and what the header copies) are read AND written by workgroup 0 only, whichever piece they belong to: no
+// other workgroup's store can land on them before they are read.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rd_sbc_chunk(int slot) { return slot + (slot >> 3); }   // (slot = sample - piece start + 16)
+static int rd_sbc_chunk_host(int slot) { return slot + (slot >> 3); }
+
+__device__ __forceinline__ double rd_load_coh(const double *p) {
+    return __builtin_bit_cast(double, __hip_atomic_load((const uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 template <int S_, int P_, uint64_t PRE_, int K_>
-__global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block_cplx(rd_sbc_args a) {
+__global__ __launch_bounds__(RD_SBC_THREADS) void k_stream_block_cplx(rd_sbc_args a) {
+    constexpr int T = RD_SBC_THREADS, C = 8 * T, PER = 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t sb_lds[];
     const int B = a.cfg.B, nwin = (2 * B) / 32, nbw = B / 32;
-    uint32_t *s_win = (uint32_t *)sb_lds;           // the 2 B-bit window
-    int32_t *s_match = (int32_t *)(s_win + nwin);   // B + 1 positions
-    __shared__ uint32_t s_nm;
+    uint32_t *s_win = (uint32_t *)sb_lds;           // the 2 B-bit window (the last workgroup)
+    uint4 *s_y = (uint4 *)(s_win + nwin);           // rotated samples -16 .. C-1 of the piece, padded (rd_sbc_chunk)
+    int32_t *s_match = (int32_t *)s_y;              // B + 1 positions: over the samples, once the signs are made
+    __shared__ uint32_t s_nm, s_last;
+    __shared__ __attribute__((aligned(4))) uint8_t s_bytes[T];
+    __shared__ double s_part[2][2][T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x, NW = gridDim.x, s0 = w * C;
     double *ring = a.ring;                          // [hdr 32 doubles][previous block 2 B][newest block 2 B]
     uint4 *r_hdr = (uint4 *)ring, *r_prev = (uint4 *)(ring + 32), *r_cur = (uint4 *)(ring + 32 + 2 * (size_t)B);  // one uint4 = one sample
     const bool have_hist = a.seen_before > 0;
-    if (tid == 0) s_nm = 0;
-    // ---- 0: the roll (py:140,154), every load before the first store ----
-    constexpr int PER = 8192 / RD_SB_THREADS;
-    uint4 nw[PER], oc[PER], ph = {0, 0, 0, 0};
+    if (w == 0) RD_SB_STAMP(0);
+    struct smp { uint64_t re, im; };   // one complex128 sample as bit patterns
+    const int in_is_u8 = a.in_is_u8;
+    const void *in = a.in;
+    auto fetch_in = [in, in_is_u8](int i) -> smp {
+        if (in_is_u8) {  // py:26,38-39
+            const uint8_t *q = (const uint8_t *)in + 2 * (size_t)i;
+            const double re = ((double)q[0] - 127.4) / 127.6, im = ((double)q[1] - 127.4) / 127.6;
+            return smp{__builtin_bit_cast(uint64_t, re), __builtin_bit_cast(uint64_t, im)};
+        }
+        const uint4 r = ((const uint4 *)in)[i];  // pinned host memory
+        return smp{((uint64_t)r.y << 32) | r.x, ((uint64_t)r.w << 32) | r.z};
+    };
+    auto fetch_ring = [](const uint4 *p) -> smp {
+        const uint4 r = *p;
+        return smp{((uint64_t)r.y << 32) | r.x, ((uint64_t)r.w << 32) | r.z};
+    };
+    auto store_coh = [](uint4 *p, smp v) {   // two 8-byte agent-scope stores
+        __hip_atomic_store((uint64_t *)p, v.re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((uint64_t *)p + 1, v.im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto rotated = [](smp x, int n) -> uint4 {  // py:46-49, x * j^(n mod 4) (rd_rot_f64), on the bit patterns: a negation flips bit 63
+        const uint64_t neg = 1ull << 63;
+        const int ph = n & 3;
+        const uint64_t re = ph == 0 ? x.re : ph == 1 ? x.im ^ neg : ph == 2 ? x.re ^ neg : x.im;
+        const uint64_t im = ph == 0 ? x.im : ph == 1 ? x.re : ph == 2 ? x.im ^ neg : x.re ^ neg;
+        return uint4{(uint32_t)re, (uint32_t)(re >> 32), (uint32_t)im, (uint32_t)(im >> 32)};
+    };
+    // ---- 0: the piece's loads, all of them before the first store ----
+    const uint4 zero4 = {0, 0, 0, 0};
+    const smp zero = {0, 0};
+    smp nw[PER], oc[PER], tl_new = zero, tl_old = zero, ph = zero, hist = zero;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int i = tid + RD_SB_THREADS * k;
-        nw[k] = uint4{0, 0, 0, 0}; oc[k] = uint4{0, 0, 0, 0};
+        const int i = s0 + tid + T * k;
+        nw[k] = zero; oc[k] = zero;
         if (i < B) {
-            if (a.in_is_u8) {  // py:26,38-39
-                const uint8_t *q = (const uint8_t *)a.in + 2 * (size_t)i;
-                const double re = ((double)q[0] - 127.4) / 127.6, im = ((double)q[1] - 127.4) / 127.6;
-                const uint2 rb = __builtin_bit_cast(uint2, re), ib = __builtin_bit_cast(uint2, im);
-                nw[k] = uint4{rb.x, rb.y, ib.x, ib.y};
-            } else {
-                nw[k] = ((const uint4 *)a.in)[i];  // pinned host memory
-            }
-            if (have_hist) oc[k] = r_cur[i];
+            nw[k] = fetch_in(i);
+            if (have_hist && i < B - 16) oc[k] = fetch_ring(&r_cur[i]);
         }
     }
-    if (have_hist && tid < 16) ph = r_prev[B - 16 + tid];  // the old previous block's last 16 samples
-    const uint32_t *win_in = a.win_in;
+    if (tid < 16) {
+        if (w == 0) {
+            tl_new = fetch_in(B - 16 + tid);
+            if (have_hist) { tl_old = fetch_ring(&r_cur[B - 16 + tid]); ph = fetch_ring(&r_prev[B - 16 + tid]); }
+            hist = tl_old;                      // (zeros without history: the zero state of py:133)
+        } else {
+            hist = fetch_in(s0 - 16 + tid);     // (the neighbour's samples, once more over the link)
+        }
+    }
+    const int wj = s0 / 32 + tid;               // this thread's word of the piece (tid < C / 32)
     uint32_t oldw = 0;
-    if (tid < nbw) oldw = win_in[nbw + tid];
-    __syncthreads();
+    if (tid < C / 32 && wj < nbw) oldw = a.win_in[nbw + wj];
+    // ---- 1: the old newest block moves down (it has been here a while), the new block follows as the link delivers it.
+    // A thread overwrites only what it has read itself.
+    if (have_hist) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = s0 + tid + T * k;
+            if (i < B - 16) store_coh(&r_prev[i], oc[k]);
+        }
+    }
+    if (tid < 16) s_y[rd_sbc_chunk(tid)] = (w > 0 || have_hist) ? rotated(hist, s0 - 16 + tid) : zero4;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int i = tid + RD_SB_THREADS * k;
+        const int i = s0 + tid + T * k;
         if (i < B) {
-            r_cur[i] = nw[k];
-            if (have_hist) r_prev[i] = oc[k];
+            if (i < B - 16) store_coh(&r_cur[i], nw[k]);
+            s_y[rd_sbc_chunk(i - s0 + 16)] = rotated(nw[k], i);
         }
     }
-    if (have_hist && tid < 16) r_hdr[tid] = ph;
-    if (tid < nbw) s_win[tid] = oldw;
-    __syncthreads();   // (the ring stores above are read below by the whole workgroup: same CU, workgroup scope)
-    // ---- 1: sign bits in float64, one 8-sample group per thread (py:46-98; taps summed in order m = 0..8) ----
-    rd_cplx_view v;
-    v.base = ring + 32 + 2 * (size_t)B;
-    v.valid_from = a.seen_before <= 0 ? 0 : a.seen_before == 1 ? -(long)B : -(long)(B + 16);
-    v.n = B;
-    for (int g = tid; g < B / 8; g += RD_SB_THREADS) {
-        const long t0 = 8 * (long)g;
-        const double c[9] = {RD_C0, RD_C1, RD_C2, RD_C3, RD_C4, RD_C3, RD_C2, RD_C1, RD_C0};
-        rd_d2 y[17];
-#pragma unroll
-        for (int i = 0; i < 17; i++) y[i] = rd_sample_f64(v, t0 - 10 + i);
+    if (w == 0 && tid < 16) {
+        if (have_hist) { store_coh(&r_hdr[tid], ph); store_coh(&r_prev[B - 16 + tid], tl_old); }
+        store_coh(&r_cur[B - 16 + tid], tl_new);
+    }
+    if (tid < C / 32 && wj < nbw) __hip_atomic_store(&a.win_out[wj], oldw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rd_barrier_lds();   // (LDS only: the ring stores drain under the arithmetic)
+    if (w == 0) RD_SB_STAMP(1);
+    // ---- 2: sign bits in float64, one 8-sample group per thread (py:52-98; taps summed in order m = 0..8) ----
+    {
+        const int t0 = s0 + 8 * tid;
         uint32_t byte = 0;
-        rd_d2 prev = {0.0, 0.0};
+        if (t0 < B) {
+            const double c[9] = {RD_C0, RD_C1, RD_C2, RD_C3, RD_C4, RD_C3, RD_C2, RD_C1, RD_C0};
+            rd_d2 y[17];
 #pragma unroll
-        for (int j = 0; j < 9; j++) {  // f[t0 - 1 + j]
-            rd_d2 f = {0.0, 0.0};
-            if (t0 - 1 + j >= v.valid_from) {
-#pragma unroll
-                for (int m = 0; m < 9; m++) {
-                    f.x += c[m] * y[j + m].x;
-                    f.y += c[m] * y[j + m].y;
-                }
+            for (int i = 0; i < 17; i++) {  // samples t0 - 10 + i
+                const uint4 x = s_y[rd_sbc_chunk(8 * tid + 6 + i)];
+                y[i].x = __builtin_bit_cast(double, uint2{x.x, x.y});
+                y[i].y = __builtin_bit_cast(double, uint2{x.z, x.w});
             }
-            if (j > 0) byte |= rd_signbit_f64(rd_disc_f64(prev, f)) << (j - 1);
-            prev = f;
+            rd_d2 prev = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 9; j++) {  // f[t0 - 1 + j]
+                rd_d2 f = {0.0, 0.0};
+                if (have_hist || t0 - 1 + j >= 0) {
+#pragma unroll
+                    for (int m = 0; m < 9; m++) {
+                        f.x += c[m] * y[j + m].x;
+                        f.y += c[m] * y[j + m].y;
+                    }
+                }
+                if (j > 0) byte |= rd_signbit_f64(prev.y * f.x - prev.x * f.y) << (j - 1);   // (py:80-90: the numerator's sign)
+                prev = f;
+            }
         }
-        ((uint8_t *)(s_win + nbw))[g] = (uint8_t)byte;
+        s_bytes[tid] = (uint8_t)byte;
+    }
+    rd_barrier_lds();
+    if (w == 0) RD_SB_STAMP(2);
+    // ---- 3: the piece's words, then the count ----
+    if (tid < C / 32 && wj < nbw)
+        __hip_atomic_store(&a.win_out[nbw + wj], ((const uint32_t *)s_bytes)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this thread is where the other workgroups read
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before + 1u == (uint32_t)NW ? 1u : 0u;
+        s_nm = 0;
     }
     __syncthreads();
-    // ---- 2: the window goes out for the state mirrors (rd_copy_quantized) and the next call ----
-    for (int i = tid; i < nwin; i += RD_SB_THREADS) a.win_out[i] = s_win[i];
-    // ---- 3: search, one 32-position word per thread; positions 0 .. B ----
-    for (int o = tid; o <= nbw; o += RD_SB_THREADS) {
+    if (w == 0) RD_SB_STAMP(3);
+    if (!s_last) return;
+#define RD_SBL_STAMP(k) do { if (a.stamps && threadIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); a.stamps[(k)] = t_; } } while (0)
+#ifndef RD_DIAG
+#undef RD_SBL_STAMP
+#define RD_SBL_STAMP(k) do { } while (0)
+#endif
+    // ---- the last workgroup: the window (every piece's words are in place), for the mirrors it is already out ----
+    if (tid == 0) __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next launch counts from 0)
+    for (int i = tid; i < nwin; i += T) s_win[i] = __hip_atomic_load(&a.win_out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    RD_SBL_STAMP(4);
+    // ---- search, one 32-position word per thread; positions 0 .. B ----
+    for (int o = tid; o <= nbw; o += T) {
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < P_; k++) {
@@ -2287,11 +2415,11 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block_cplx(rd_sbc_args
         }
     }
     __syncthreads();
+    RD_SBL_STAMP(5);
     const uint32_t nm = s_nm;
-    // ---- 4: slice + RSSI / SNR, one wave per match ----
+    // ---- slice: a wave per match decides whether the match is superseded (a neighbour's identical bytes come first) ----
     rd_packet *recs = a.recs_host;
-    for (uint32_t i = (uint32_t)wave; i < nm; i += RD_SB_THREADS / 64) {
-        const int pos = __builtin_amdgcn_readfirstlane(s_match[i]);
+    auto bytes_of = [&](int pos, bool &superseded) -> uint32_t {   // lane bi < 10: byte bi of the packet at `pos`
         uint32_t byte = 0;
         bool same_prev = true, same_next = true;
         for (int r = 0; r * 64 < K_; r++) {
@@ -2309,30 +2437,109 @@ __global__ __launch_bounds__(RD_SB_THREADS) void k_stream_block_cplx(rd_sbc_args
         }
         const uint32_t phs = (uint32_t)pos % (uint32_t)S_;
         const bool prev_first = S_ == 1 || phs != 0, next_first = S_ > 1 && phs == S_ - 1;
-        const bool superseded = (same_prev && pos >= 1 && prev_first) || (same_next && pos + 1 <= B && next_first);
+        superseded = (same_prev && pos >= 1 && prev_first) || (same_next && pos + 1 <= B && next_first);
+        return byte;
+    };
+    for (uint32_t i = (uint32_t)wave; i < nm; i += T / 64) {
+        const int pos = __builtin_amdgcn_readfirstlane(s_match[i]);
+        bool superseded;
+        (void)bytes_of(pos, superseded);
         if (superseded) {
             rd_store_void(nullptr, &recs[i], lane);
-            continue;
+            if (lane == 0) s_match[i] = pos | 0x40000000;
         }
-        double rssi = 0.0, snr = 0.0;
-        rd_rssi_f64(v, 0, a.cfg, (long)pos, lane, rssi, snr);
-        rd_store_record(nullptr, &recs[i], lane, 0, (long)a.seen_before, (long)pos, a.cfg.nbytes, byte, rssi, snr);
     }
-    // ---- 5: count, fence, flag ----
+    __syncthreads();
+    // ---- RSSI / SNR of the others, one after the other, the whole workgroup on each (rd_rssi_f64's sums: |f|^2 over
+    // [q - PL, q) and [q, q + PL), clipped to the newest block's filtered outputs, py:216-246).  A thread takes NINE
+    // consecutive outputs: their 17 samples are asked for at once and slide through the taps - one round trip to where
+    // the other workgroups' ring stores went, where an output per lane and trip (rd_rssi_f64) makes one per 64 outputs.
+    const long vfrom = a.seen_before <= 0 ? 0 : a.seen_before == 1 ? -(long)B : -(long)(B + 16);
+    const double *cur = ring + 32 + 2 * (size_t)B;   // sample 0 of the newest block
+    uint32_t parity = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        const int pm = s_match[i];   // (uniform: every thread reads the same word)
+        if (pm & 0x40000000) continue;
+        const long q = pm;
+        const long ns = q - a.cfg.PL < 0 ? 0 : q - a.cfg.PL;
+        const long pe = q + a.cfg.PL > B + 1 ? B + 1 : q + a.cfg.PL;
+        double noise = 0.0, sig = 0.0;
+        constexpr int R = 9;
+        for (long j0 = ns + (long)tid * R; j0 < pe; j0 += (long)T * R) {
+            // outputs j0 .. j0 + 8 are f[j0 - 1 .. j0 + 7]: samples j0 - 10 .. j0 + 6
+            const double c[9] = {RD_C0, RD_C1, RD_C2, RD_C3, RD_C4, RD_C3, RD_C2, RD_C1, RD_C0};
+            rd_d2 y[R + 8];
+#pragma unroll
+            for (int k = 0; k < R + 8; k++) {
+                const long n = j0 - 10 + k;
+                y[k] = rd_d2{0.0, 0.0};
+                if (n >= vfrom && n < B) y[k] = rd_rot_f64(rd_load_coh(cur + 2 * n), rd_load_coh(cur + 2 * n + 1), n);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const long j = j0 + r;
+                rd_d2 f = {0.0, 0.0};
+                if (j - 1 >= vfrom) {
+#pragma unroll
+                    for (int m = 0; m < 9; m++) {
+                        f.x += c[m] * y[r + m].x;
+                        f.y += c[m] * y[r + m].y;
+                    }
+                }
+                const double p = f.x * f.x + f.y * f.y;
+                if (j < pe) { if (j < q) noise += p; else sig += p; }
+            }
+        }
+        noise = rd_wave_sum(noise);
+        sig = rd_wave_sum(sig);
+        if (lane == 0) { s_part[parity][0][wave] = noise; s_part[parity][1][wave] = sig; }
+        __syncthreads();
+        if (wave == 0) {
+            bool superseded;
+            const uint32_t byte = bytes_of((int)q, superseded);
+            double rssi = 0.0, snr = 0.0;
+            if (lane == 0) {
+                double nsum = 0.0, ssum = 0.0;
+#pragma unroll
+                for (int k = 0; k < T / 64; k++) { nsum += s_part[parity][0][k]; ssum += s_part[parity][1][k]; }
+                const double noise_power = (q > ns) ? nsum / (double)(q - ns) : 1e-9;
+                const double signal_power = (pe > q) ? ssum / (double)(pe - q) : __builtin_nan("");
+                rssi = signal_power > 0 ? 10.0 * log10(signal_power) : -120.0;
+                snr = noise_power > 0 ? 10.0 * log10(signal_power / noise_power) : 50.0;
+            }
+            rd_store_record(nullptr, &recs[i], lane, 0, (long)a.seen_before, q, a.cfg.nbytes, byte, rssi, snr);
+        }
+        parity ^= 1u;   // (the next match's partial sums go to the other set: one barrier per match)
+    }
+    // ---- count, fence, flag ----
     __syncthreads();
     if (tid == 0) {
         a.cnt_host[0] = nm;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: records and count before the flag
         __hip_atomic_store(&a.flag_host[0], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    RD_SBL_STAMP(6);
 }
 
-int rd_launch_stream_block_cplx(const rd_sbc_args &a, hipStream_t st) {
-    const rd_devcfg &c = a.cfg;
-    if (!(c.S == 14 && c.P == 16 && c.K == 80 && c.pre_mask == 0x91D3ull) || c.L != 2 * c.B || c.B % 32 || c.B < 2048 || c.B > 8192)
+int rd_launch_stream_block_cplx(const rd_sbc_args &a_in, hipStream_t st) {
+    const rd_devcfg &c = a_in.cfg;
+    if (!(c.S == 14 && c.P == 16 && c.K == 80 && c.pre_mask == 0x91D3ull) || c.L != 2 * c.B || c.B % 32 || c.B < 2048 || c.B > 8192 ||
+        !a_in.sync)
         return 0;
-    const size_t lds = (size_t)(2 * c.B / 32) * 4 + ((size_t)c.B + 1) * 4;
-    hipLaunchKernelGGL((k_stream_block_cplx<14, 16, 0x91D3ull, 80>), dim3(1), dim3(RD_SB_THREADS), lds, st, a);
+    rd_sbc_args a = a_in;
+    a.stamps = nullptr;
+#ifdef RD_DIAG
+    a.stamps = rd_sb_stamp_buffer();
+#endif
+    constexpr int C = 8 * RD_SBC_THREADS;
+    const int chunks = rd_sbc_chunk_host(C + 16) + 1;
+    const size_t lds = (size_t)(2 * c.B / 32) * 4 + std::max((size_t)chunks * 16, ((size_t)c.B + 1) * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_stream_block_cplx<14, 16, 0x91D3ull, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_stream_block_cplx<14, 16, 0x91D3ull, 80>), dim3((unsigned)((c.B + C - 1) / C)), dim3(RD_SBC_THREADS), lds, st, a);
     return 1;
 }
 
