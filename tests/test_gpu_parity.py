@@ -517,6 +517,45 @@ def test_one_launch_block_at_other_block_sizes(dsp, B):
     assert again == [x for x in single if x[0] < min(nb, 6)]
 
 
+@pytest.mark.parametrize("B", [2048, 2144, 4096, 6176, 8192])
+def test_one_launch_complex_block_at_other_block_sizes(dsp, B):
+    """The complex-input one-launch form (k_stream_block_cplx, dsp.py:144-150 + 154-246) cuts a block into pieces of 2048
+    samples, a workgroup each, and the last workgroup to arrive searches and slices: one piece (2048), a ragged second
+    piece (2144), two, a ragged fourth (6176) and four (8192).  Input = the byte stream through the reference's LUT
+    (py:26), so the per-call lists equal the C oracle's for the bytes (index, bytes, order exactly; RSSI / SNR to
+    1e-3 dB), block by block over a whole stream; then reset(), uint8 blocks first and complex ones behind them (the
+    byte ring converted once, history carried over: py:150-152), and the quantized mirror against the oracle's bits."""
+    from oracle import c_oracle as CO
+    raw = synth.synth_streams([4])
+    nb = raw.shape[1] // (2 * B)
+    raw = np.ascontiguousarray(raw[:, : 2 * B * nb])
+    cfg = dsp.PacketConfig(19200, 14, 16, 80, "1100101110001001", B)
+    want, bits = CO.demod_batch(raw, CO.make_cfg(19200, 14, 16, 80, "1100101110001001", B), threads=2, want_bits=True, cap_per_stream=256)
+    exp = [(p.call, p.index, bytes(p.data).hex(), p.rssi, p.snr) for p in want[0]]
+    assert exp
+    lut = (np.arange(256, dtype=np.float64) - 127.4) / 127.6
+    cplx = lut[raw[0, 0::2]] + 1j * lut[raw[0, 1::2]]
+    dem = dsp.Demodulator(cfg)
+
+    def run(first_complex):
+        got = []
+        for b in range(nb):
+            blk = cplx[B * b: B * (b + 1)] if b >= first_complex else raw[0, 2 * B * b: 2 * B * (b + 1)]
+            got += [(b, p.index, bytes(p.data).hex(), p.rssi, p.snr) for p in dem.demodulate(blk)]
+        return got
+
+    for first_complex in (0, 3):
+        dem.reset()
+        got = run(first_complex)
+        assert [g[:3] for g in got] == [e[:3] for e in exp], (B, first_complex)
+        for g, e in zip(got, exp):
+            assert abs(g[3] - e[3]) < 1e-3 and abs(g[4] - e[4]) < 1e-3
+        # the window after the last block = the stream's last 2 B sign bits
+        q = np.asarray(dem.quantized).astype(np.uint8)
+        allbits = np.unpackbits(bits[0], bitorder="little")[: B * nb]
+        assert np.array_equal(q, allbits[-2 * B:]), (B, first_complex)
+
+
 def test_submit_fetch_pipeline_equals_synchronous_path(dsp, golden_streams):
     """rd_demod_submit / rd_demod_fetch with two blocks in flight over a 33-block stream: the same
     packets (index, bytes, order, RSSI/SNR) as demodulate() block by block, and as the reference."""
