@@ -63,6 +63,8 @@ timeout -k 10 300 python3 $ROOT/bench.py --no-cpu-baseline --live-traffic 0 --su
 tail -c 500 $OUT/host_fed.json | tee -a $OUT/progress.log
 RTLDAVIS_HIP_LIB=$ROOT/rtldavis_amd/librtldavis_hip_diag.so RD_FT_STAMPS=1 timeout -k 10 300 python3 $ROOT/tools/tail_stamps.py > $OUT/tail_stamps.txt 2>&1
 cat $OUT/tail_stamps.txt | tee -a $OUT/progress.log
+RTLDAVIS_HIP_LIB=$ROOT/rtldavis_amd/librtldavis_hip_diag.so RD_SB_STAMPS=1 timeout -k 10 300 python3 $ROOT/tools/stream_stamps.py > $OUT/stream_stamps.txt 2>&1
+cat $OUT/stream_stamps.txt | tee -a $OUT/progress.log
 
 step "9/9 N = 2 rehearsal on one GPU (code path only, not a measurement)"
 timeout -k 10 400 python3 $ROOT/bench.py --gpus 2 --steps 6 --warmup 2 --rehearse-shared-gpu --streams 1024 --sustain 0 > $OUT/rehearse_shared_gpu.txt 2>&1
