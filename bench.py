@@ -195,10 +195,14 @@ def wideband(args):
     for _ in range(args.steps):
         recs = step()
     dt = (time.perf_counter() - t0) / args.steps
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # (the library's own HIP runtime: already loaded)
+    hip.hipDeviceSynchronize()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         cz.run_into(bd)
-    cz.run_host(1)  # synchronous copy: drains the stream
+    if hip.hipDeviceSynchronize() != 0:  # (the launches above are on the null stream)
+        raise SystemExit("bench.py --wideband: hipDeviceSynchronize failed")
     dt_c = (time.perf_counter() - t1) / args.steps
     ok = sum(payload in [r["data"][: int(r["nbytes"])].tobytes().hex() for r in recs if int(r["stream"]) == c]
              for c, (payload, _s) in enumerate(info))
