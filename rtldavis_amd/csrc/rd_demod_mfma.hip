@@ -185,8 +185,19 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
                                              uint32_t &Whi, uint32_t &fblo, uint32_t &fbhi, bool &slow, float *dg, int dleft) {
     const rd_h8 bfB = rd_mf_frag(D[B + 1]);
     __builtin_amdgcn_sched_barrier(0);
-    rd_f16v acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], bfA, dcC, 0, 0, 0);  // C: -D_hi in the hi rows
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], bfB, acc, 0, 0, 0);
+    rd_f16v acc;
+    if (DBG == 8 || DBG == 9) {
+        // WRONG results, timing only: ONE matrix instruction per block - what a 2:4-sparse v_smfmac_f32_32x32x32_f16 would
+        // issue (the tap rows are 2:4 sparse).  9: with the copy of the DC term into the accumulators that instruction
+        // needs (it has no C operand)
+        rd_f16v c0 = dcC;
+        if (DBG == 9) asm volatile("" : "+v"(c0));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], bfA, c0, 0, 0, 0);
+        asm volatile("" : : "v"(bfB));
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], bfA, dcC, 0, 0, 0);  // C: -D_hi in the hi rows
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], bfB, acc, 0, 0, 0);
+    }
     // the previous block's finish runs under these two (block 0's waits for the end of the tile)
     if (B >= 2) rd_mf8_finish<B - 1, DBG>(kp, p, B - 1 <= 3 ? Wlo : Whi, B - 1 <= 3 ? fblo : fbhi, slow);
     __builtin_amdgcn_sched_barrier(0);
@@ -198,12 +209,14 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
         for (int r = 0; r < 4; r++)  // the tile's last output (column 31, half 1, block 7, r' = 3) belongs to the next tile
             if (8 * B + r < dleft) { dg[2 * (8 * B + r)] = g[2 * r]; dg[2 * (8 * B + r) + 1] = g[2 * r + 1]; }
     }
-    {
+    if (DBG != 10) {   // (10 - WRONG results, timing only: without the predecessor exchange's LDS traffic)
         const rd_f4v x = {g[4], g[5], g[6], g[7]};
         if (B == 7) rd_lds_write16<0>(ad.xw7, x);
         else rd_lds_write16<rd_mf8_woff<B>()>(ad.xw, x);
+    } else {
+        asm volatile("" : : "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]));
     }
-    if (B >= 1) p = rd_lds_read16<0>(B == 1 ? ad.rd1 : (B & 1) ? ad.rdO : ad.rdE);  // consumed one block later
+    if (B >= 1 && DBG != 10) p = rd_lds_read16<0>(B == 1 ? ad.rd1 : (B & 1) ? ad.rdO : ad.rdE);  // consumed one block later
     rd_mf8_kept &k = B == 0 ? k0 : kp;
     float t2, t3;
     k.n2 = rd_mf_num(g[0], g[1], g[2], g[3], t2);
@@ -820,6 +833,9 @@ bool rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
             case 2: rd_mf_launch_variant<2, false>(a); return false;
             case 6: rd_mf_launch_variant<6, false>(a); return false;
             case 7: rd_mf_launch_variant<7, false>(a); return false;
+            case 8: rd_mf_launch_variant<8, false>(a); return false;
+            case 9: rd_mf_launch_variant<9, false>(a); return false;
+            case 10: rd_mf_launch_variant<10, false>(a); return false;
             default:
                 fprintf(stderr, "[rd diag] no kernel variant RD_K1_DEBUG=%d RD_K1_STAMPS=%d is compiled in\n", P.dbg, P.stamp);
                 abort();

@@ -556,6 +556,35 @@ def test_one_launch_complex_block_at_other_block_sizes(dsp, B):
         assert np.array_equal(q, allbits[-2 * B:]), (B, first_complex)
 
 
+def test_complex_blocks_equal_the_reference_on_every_fixture_stream(dsp, golden_streams):
+    """All 64 fixture streams block by block as complex128 (the bytes through the reference's LUT, py:26: what the
+    reference keeps in raw_samples either way, py:150-152) through ONE handle with reset() in between: the per-call
+    lists of the real reference (tests/golden/streams.json: index, bytes, order; RSSI / SNR to 1e-3 dB), and
+    submit() / fetch() with two blocks in flight gives the same lists as the synchronous calls."""
+    cfg = prod_cfg(dsp)
+    lut = (np.arange(256, dtype=np.float64) - 127.4) / 127.6
+    dem = dsp.Demodulator(cfg)
+    B = 8192
+    n = 0
+    for seed in sorted(golden_streams, key=int):
+        raw = synth.synth_stream(int(seed))
+        cplx = lut[raw[0::2]] + 1j * lut[raw[1::2]]
+        dem.reset()
+        calls = [dem.demodulate(cplx[B * b: B * (b + 1)]) for b in range(synth.BLOCKS_PER_STREAM)]
+        assert_calls_equal(calls, dense_calls(golden_streams[seed]["calls"], synth.BLOCKS_PER_STREAM))
+        n += sum(len(c) for c in calls)
+        if int(seed) % 8 == 0:
+            dem.reset()
+            piped = []
+            dem.submit(cplx[:B])
+            for b in range(1, synth.BLOCKS_PER_STREAM):
+                dem.submit(cplx[B * b: B * (b + 1)])
+                piped.append(dem.fetch())
+            piped.append(dem.fetch())
+            assert_calls_equal(piped, dense_calls(golden_streams[seed]["calls"], synth.BLOCKS_PER_STREAM))
+    assert n >= len(golden_streams)
+
+
 def test_submit_fetch_pipeline_equals_synchronous_path(dsp, golden_streams):
     """rd_demod_submit / rd_demod_fetch with two blocks in flight over a 33-block stream: the same
     packets (index, bytes, order, RSSI/SNR) as demodulate() block by block, and as the reference."""

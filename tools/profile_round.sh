@@ -38,7 +38,7 @@ cat $OUT/traffic.json | tee -a $OUT/progress.log
 step "5/9 ablations of the demod kernel (tools/k1_ab.py, diagnostic library: librtldavis_hip_diag.so)"
 # RD_AB_TIMING=1: demod kernel + whole run.  RD_K1_DEBUG (wrong results): 1 compute only, 2 loads + stores only, 6 loads only,
 # 7 no guard band; valu = the round-1 kernel; legacy_tail = the separate tail kernels + host ordering
-RD_AB_TIMING=1 timeout -k 10 700 python3 $ROOT/tools/k1_ab.py --key all --rounds 2 product no_guard=RD_K1_DEBUG=7 compute_only=RD_K1_DEBUG=1 loads_stores_only=RD_K1_DEBUG=2 loads_only=RD_K1_DEBUG=6 plain_stores=RD_K1_STFLAGS=1 valu=RD_K1_IMPL=valu wgs3=RD_K1_WGS_PER_CU=3 chunk8=RD_K1_CHUNK=8 chunk28=RD_K1_CHUNK=28 legacy_tail=RD_TAIL_IMPL=legacy > $OUT/ablation.txt 2>&1
+RD_AB_TIMING=1 timeout -k 10 700 python3 $ROOT/tools/k1_ab.py --key all --rounds 2 product no_guard=RD_K1_DEBUG=7 compute_only=RD_K1_DEBUG=1 loads_stores_only=RD_K1_DEBUG=2 loads_only=RD_K1_DEBUG=6 plain_stores=RD_K1_STFLAGS=1 valu=RD_K1_IMPL=valu wgs3=RD_K1_WGS_PER_CU=3 chunk8=RD_K1_CHUNK=8 chunk28=RD_K1_CHUNK=28 half_mfma=RD_K1_DEBUG=8 half_mfma_init=RD_K1_DEBUG=9 no_exchange=RD_K1_DEBUG=10 legacy_tail=RD_TAIL_IMPL=legacy > $OUT/ablation.txt 2>&1
 cat $OUT/ablation.txt | tee -a $OUT/progress.log
 
 step "6/9 wideband (channelizer) line and its kernel stats"
