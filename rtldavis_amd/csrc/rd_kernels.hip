@@ -2048,8 +2048,12 @@ __device__ __forceinline__ uint32_t rd_lds_bits32(const uint32_t *w, int nwords,
 // diagnostic library: s_memrealtime stamps of the streaming blocks' phases (stream 0's workgroup), RD_SB_STAMPS=1
 #define RD_SB_STAMP(k) do { if (a.stamps && threadIdx.x == 0 && blockIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
                                                                                  a.stamps[(k)] = t_; } } while (0)
+// (the same from whichever workgroup gets there: k_stream_block_cplx's last workgroup)
+#define RD_SBL_STAMP(k) do { if (a.stamps && threadIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); \
+                                                              a.stamps[(k)] = t_; } } while (0)
 #else
 #define RD_SB_STAMP(k) do { } while (0)
+#define RD_SBL_STAMP(k) do { } while (0)
 #endif
 #ifdef RD_DIAG
 static uint64_t *g_sb_stamps = nullptr;
@@ -2388,11 +2392,6 @@ __global__ __launch_bounds__(RD_SBC_THREADS) void k_stream_block_cplx(rd_sbc_arg
     __syncthreads();
     if (w == 0) RD_SB_STAMP(3);
     if (!s_last) return;
-#define RD_SBL_STAMP(k) do { if (a.stamps && threadIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); a.stamps[(k)] = t_; } } while (0)
-#ifndef RD_DIAG
-#undef RD_SBL_STAMP
-#define RD_SBL_STAMP(k) do { } while (0)
-#endif
     // ---- the last workgroup: the window (every piece's words are in place), for the mirrors it is already out ----
     if (tid == 0) __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next launch counts from 0)
     for (int i = tid; i < nwin; i += T) s_win[i] = __hip_atomic_load(&a.win_out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
