@@ -141,6 +141,18 @@ int rd_demod_blocks(rd_demod *h, const uint8_t *iq, size_t nbytes, rd_packet *ou
  */
 int rd_demod_submit(rd_demod *h, const void *samples, size_t count, int is_complex);
 /*
+ * How rd_demod_submit hands a block to the device.  Where the whole of device memory is host-visible (PCIe large BAR:
+ * hipDeviceAttributeIsLargeBar) and the runtime publishes the device's HDP flush register, the one-launch forms take the
+ * block from an uncached DEVICE buffer the host has written it into (memcpy, sfence, HDP flush, launch: 128 KB in ~3 us
+ * at ~45 GB/s) instead of reading a pinned host slot across the bus from inside the kernel (~13 GB/s).  Same packets
+ * either way.  rd_set_input_push: -1 = use the push where available (default; RD_PUSH_INPUT=0 in the environment turns
+ * it off), 0 = never, 1 = as -1; applies to handles whose device state is created afterwards; returns 1 when the push
+ * is available on the current device (0 otherwise, < 0 on a device error).  rd_demod_input_mode: 1 when this handle's
+ * copied blocks are pushed, 0 when they go through the pinned slot.
+ */
+int rd_set_input_push(int mode);
+int rd_demod_input_mode(rd_demod *h);
+/*
  * The same without ANY copy on the way in - SURVEY section 8f-4's "pinned-memory ring replacing the pickled-ndarray
  * queue hop" (/root/reference/src/rtldavis/runners/rtlsdr.py:100-103 `data_queue.put(samples)` ->
  * /root/reference/src/rtldavis/worker.py:37 `data_queue.get()`): rd_demod_register_input pins a buffer the PRODUCER owns

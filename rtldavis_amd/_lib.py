@@ -54,6 +54,8 @@ SIGNATURES = {
     "rd_device_count": (C.c_int, []),
     "rd_set_device": (C.c_int, [C.c_int]),
     "rd_set_wait_timeout_ms": (C.c_int, [C.c_int]),
+    "rd_set_input_push": (C.c_int, [C.c_int]),
+    "rd_demod_input_mode": (C.c_int, [C.c_void_p]),
     "rd_create": (C.c_int, [C.POINTER(RdConfig), C.POINTER(_P)]),
     "rd_create_multi": (C.c_int, [C.POINTER(RdConfig), C.c_int, C.POINTER(_P)]),
     "rd_demod_blocks": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(RdPacket), C.c_int, C.POINTER(C.c_int)]),

@@ -5,6 +5,9 @@
 // the kernels of rd_kernels.hip; there is no CPU fallback - without a usable HIP device
 // every compute entry point returns RD_ERR_DEVICE.
 #include <unistd.h>
+#include <immintrin.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -897,10 +900,75 @@ extern "C" int rd_batch_get_counters(rd_batch *b, uint64_t *fixup_runs, uint64_t
 // streaming demodulator (py:128-253)
 // ------------------------------------------------------------------------------------------
 // One block in flight: pinned input, its device staging copy, pinned counters and mapped records.
+// ------------------------------------------------------------------------------------------
+// Host push (streaming handle).  A kernel's own reads of pinned host memory run at ~13 GB/s however many CUs ask
+// (profiles/r04_stream_stamps.txt: a complex128 block's 128 KB = 10 of the kernel's 15 us), the host's stores into device
+// memory through the PCIe BAR at ~45 GB/s (tools/ubench/bar_write.hip: 128 KB in 2.9 us).  Where the whole of device memory
+// is host-visible (hipDeviceAttributeIsLargeBar) rd_demod_submit therefore copies the block straight into an UNCACHED
+// device buffer (no stale line in an XCD's L2 when the slot is written again), makes the stores leave the CPU's
+// write-combining buffers (sfence), flushes the GPU's host data path (HDP: the register ROCr publishes for exactly this,
+// HSA_AMD_AGENT_INFO_HDP_FLUSH) and launches; PCIe keeps posted writes in order, so the block is in HBM before the launch's
+// doorbell arrives.  Without a large BAR, without the register, or with RD_PUSH_INPUT=0: the pinned slot, as before.
+// ------------------------------------------------------------------------------------------
+#define RD_MAX_DEVICES 64
+struct rd_push_info {
+    int state = 0;                        // 0 not probed, 1 available, -1 not available
+    volatile uint32_t *hdp_flush = nullptr;
+};
+static rd_push_info g_push[RD_MAX_DEVICES];
+
+struct rd_hdp_find { uint32_t bdf, domain; volatile uint32_t *reg; bool found; };
+static hsa_status_t rd_hdp_cb(hsa_agent_t agent, void *data) {
+    rd_hdp_find *f = (rd_hdp_find *)data;
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, dom = 0;
+    if (hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (bdf != f->bdf || dom != f->domain) return HSA_STATUS_SUCCESS;
+    hsa_amd_hdp_flush_t h = {nullptr, nullptr};
+    if (hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &h) == HSA_STATUS_SUCCESS) f->reg = h.HDP_MEM_FLUSH_CNTL;
+    f->found = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+
+// 1 when the host may write blocks straight into device memory of `dev` (and knows how to flush the HDP behind them)
+static int g_push_mode = -1;   // rd_set_input_push: 0 = never
+static bool push_available(int dev) {
+    if (dev < 0 || dev >= RD_MAX_DEVICES || g_push_mode == 0) return false;
+    rd_push_info &p = g_push[dev];
+    if (p.state) return p.state > 0;
+    p.state = -1;
+    const char *e = getenv("RD_PUSH_INPUT");
+    if (e && atoi(e) == 0) return false;
+    int large = 0;
+    if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess || !large) return false;
+    char id[64] = {0};
+    unsigned dom = 0, bus = 0, d = 0, fn = 0;
+    if (hipDeviceGetPCIBusId(id, sizeof id, dev) != hipSuccess || sscanf(id, "%x:%x:%x.%x", &dom, &bus, &d, &fn) != 4) return false;
+    if (hsa_init() != HSA_STATUS_SUCCESS) return false;   // (a reference on the runtime HIP already runs on; kept)
+    rd_hdp_find f = {(bus << 8) | (d << 3) | fn, dom, nullptr, false};
+    hsa_iterate_agents(rd_hdp_cb, &f);
+    if (!f.found || !f.reg) return false;
+    p.hdp_flush = f.reg;
+    p.state = 1;
+    return true;
+}
+
+extern "C" int rd_set_input_push(int mode) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    g_push_mode = mode == 0 ? 0 : -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(RD_ERR_DEVICE, "hipGetDevice failed");
+    return push_available(dev) ? 1 : 0;
+}
+
 struct rd_slot {
     uint8_t *h_in = nullptr;         // pinned + mapped: NS x 2B bytes (or B complex128)
     uint8_t *d_in_map = nullptr;     // device address of h_in (the one-launch block reads its input from there)
     uint8_t *d_in = nullptr;         // device staging: the H2D copy lands here on the copy stream
+    uint8_t *d_push = nullptr;       // uncached device memory the HOST writes the block into (large BAR), or null
     uint32_t *h_cnt = nullptr;       // pinned
     rd_packet *h_recs = nullptr;     // pinned + mapped, rec_cap entries: written by the slice kernel
     rd_packet *d_recs_map = nullptr; // device address of h_recs
@@ -1001,6 +1069,10 @@ static int demod_alloc(rd_demod *h) {
         HIPCHK(hipHostMalloc((void **)&sl.h_in, in_bytes, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&sl.d_in_map, sl.h_in, 0));
         HIPCHK(hipMalloc(&sl.d_in, in_bytes));
+        if (push_available(h->device) && hipExtMallocWithFlags((void **)&sl.d_push, in_bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            sl.d_push = nullptr;   // (the pinned slot serves)
+        }
         HIPCHK(hipHostMalloc((void **)&sl.h_sb, 2 * NS * sizeof(uint32_t), hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&sl.d_sb_map, sl.h_sb, 0));
         memset(sl.h_sb, 0, 2 * NS * sizeof(uint32_t));
@@ -1061,7 +1133,7 @@ extern "C" void rd_destroy(rd_demod *h) {
         hipHostFree(h->h_tmp);
         for (int i = 0; i < 2; i++) {
             rd_slot &sl = h->slot[i];
-            hipHostFree(sl.h_in); hipFree(sl.d_in); hipHostFree(sl.h_cnt); hipHostFree(sl.h_recs); hipHostFree(sl.h_sb);
+            hipHostFree(sl.h_in); hipFree(sl.d_in); hipFree(sl.d_push); hipHostFree(sl.h_cnt); hipHostFree(sl.h_recs); hipHostFree(sl.h_sb);
             if (sl.e_in) hipEventDestroy(sl.e_in);
             if (sl.e_done) hipEventDestroy(sl.e_done);
         }
@@ -1202,9 +1274,19 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex, long e
     hipStream_t st = h->st;
     const size_t nbytes = is_complex ? 2 * B * sizeof(double) : NS * 2 * B;
     const uint8_t *in_host = sl.h_in, *in_dev = sl.d_in_map;   // where this block's bytes are, host and device address
+    const bool will_one = h->one_ok && (is_complex || h->cplx_mode ? (NS == 1 && h->dc.B <= 8192) : true);
+    bool pushed = false;
     if (ext_off >= 0) {
         in_host = h->ext_host + ext_off;
         in_dev = h->ext_dev + ext_off;
+    } else if (will_one && sl.d_push) {
+        // the host writes the block into device memory (see rd_push_info): stores out of the write-combining buffers,
+        // then the HDP flush, then - in posted order behind both - the launch's doorbell
+        memcpy(sl.d_push, samples, nbytes);
+        _mm_sfence();
+        *g_push[h->device].hdp_flush = 1u;
+        in_dev = sl.d_push;
+        pushed = true;
     } else {
         memcpy(sl.h_in, samples, nbytes);
     }
@@ -1269,6 +1351,7 @@ static int demod_submit(rd_demod *h, const void *samples, int is_complex, long e
         }
         --h->seq;
     }
+    if (pushed) memcpy(sl.h_in, samples, nbytes);   // (the one-launch form declined: the multi-launch form copies from the pinned slot)
     HIPCHK(hipMemcpyAsync(sl.d_in, in_host, nbytes, hipMemcpyHostToDevice, h->st_copy));
     HIPCHK(hipEventRecord(sl.e_in, h->st_copy));
     HIPCHK(hipStreamWaitEvent(st, sl.e_in, 0));
@@ -1414,6 +1497,13 @@ extern "C" int rd_demod_register_input(rd_demod *h, void *host, size_t nbytes) {
     h->ext_dev = (uint8_t *)dev;
     h->ext_bytes = nbytes;
     return RD_OK;
+}
+
+extern "C" int rd_demod_input_mode(rd_demod *h) {
+    if (!h) return fail(RD_ERR_ARG, "null handle");
+    int rc = demod_alloc(h);
+    if (rc) return rc;
+    return h->slot[0].d_push && h->slot[1].d_push ? 1 : 0;
 }
 
 extern "C" int rd_demod_submit_from(rd_demod *h, size_t offset, size_t count, int is_complex) {

@@ -2238,11 +2238,12 @@ int rd_launch_stream_block(const rd_sb_args &a_in, int n_streams, hipStream_t st
 //      (finite input; a NaN numerator has no sign to agree on)
 //   3  the piece's sign words into the window; then the workgroup counts itself in.  The LAST one to arrive goes on
 //      alone: window, search, slice, RSSI / SNR, records, flag (k_stream_block's steps 2 - 5)
-// What one workgroup writes and another reads in the same launch - the ring (the RSSI windows reach into other pieces
-// and the previous block) and the window's words - travels as relaxed agent-scope atomics (sc1: written through to,
-// read from the level all XCDs share), each store acknowledged (s_waitcnt vmcnt(0)) before the workgroup's increment of
-// the arrival counter; no release / acquire fence (an L2 write-back and invalidate at agent scope, see k_tail).  Nobody
-// waits for anybody: a workgroup that is not the last simply ends.  The ring's last 16 samples (next block's filter
+// What one workgroup writes and another reads in the same launch: the window's words travel as relaxed agent-scope
+// atomics (sc1: written through to, read from the level all XCDs share); the ring (the RSSI windows reach into other
+// pieces and the previous block) is written with plain stores and ONE agent-scope release per wave in front of the
+// workgroup's increment of the arrival counter (a write-back of this XCD's few dirty L2 lines: 0.6 us; the same ring as
+// 32 write-through stores per thread took 6 us of issue) and read by the last workgroup with sc1 loads.  Nobody waits
+// for anybody: a workgroup that is not the last simply ends.  The ring's last 16 samples (next block's filter
 // history, and what the header copies) are read AND written by workgroup 0 only, whichever piece they belong to: no
 // other workgroup's store can land on them before they are read.
 // ------------------------------------------------------------------------------------------
@@ -2286,9 +2287,8 @@ __global__ __launch_bounds__(RD_SBC_THREADS) void k_stream_block_cplx(rd_sbc_arg
         const uint4 r = *p;
         return smp{((uint64_t)r.y << 32) | r.x, ((uint64_t)r.w << 32) | r.z};
     };
-    auto store_coh = [](uint4 *p, smp v) {   // two 8-byte agent-scope stores
-        __hip_atomic_store((uint64_t *)p, v.re, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((uint64_t *)p + 1, v.im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto store_coh = [](uint4 *p, smp v) {   // (plain 16-byte store: the release fence in front of the count writes the L2 back)
+        *p = uint4{(uint32_t)v.re, (uint32_t)(v.re >> 32), (uint32_t)v.im, (uint32_t)(v.im >> 32)};
     };
     auto rotated = [](smp x, int n) -> uint4 {  // py:46-49, x * j^(n mod 4) (rd_rot_f64), on the bit patterns: a negation flips bit 63
         const uint64_t neg = 1ull << 63;
@@ -2382,7 +2382,10 @@ __global__ __launch_bounds__(RD_SBC_THREADS) void k_stream_block_cplx(rd_sbc_arg
     // ---- 3: the piece's words, then the count ----
     if (tid < C / 32 && wj < nbw)
         __hip_atomic_store(&a.win_out[nbw + wj], ((const uint32_t *)s_bytes)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this thread is where the other workgroups read
+    // the piece's ring stores are plain stores into this XCD's L2: one agent-scope release per wave (a write-back of the
+    // L2's dirty lines - few here - and a wait for every store) puts them where the last workgroup's sc1 loads read.
+    // (32 write-through stores per thread instead cost 6 us of issue: the vector memory queue backs up behind them.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
         const uint32_t before = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

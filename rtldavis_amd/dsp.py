@@ -242,6 +242,15 @@ class Demodulator:
     def inflight(self) -> int:
         return int(_lib.lib().rd_demod_inflight(self._handle()))
 
+    @property
+    def input_pushed(self) -> bool:
+        """True when this handle's copied blocks are written by the host straight into device memory (PCIe large BAR),
+        False when the kernel reads them from a pinned host slot (``set_input_push``)."""
+        rc = int(_lib.lib().rd_demod_input_mode(self._handle()))
+        if rc < 0:
+            _lib.check(rc)
+        return rc == 1
+
     def reset(self) -> None:
         _lib.check(_lib.lib().rd_reset(self._handle()))
 
@@ -343,6 +352,16 @@ class MultiDemodulator:
         out = np.empty(2 * self.cfg.block_size, dtype=np.float64)
         _lib.check(_lib.lib().rd_copy_discriminated_stream(self._h, int(stream), out.ctypes.data, out.size))
         return out
+
+
+def set_input_push(on: Optional[bool] = None) -> bool:
+    """How the streaming handles created AFTERWARDS get their copied blocks onto the device: None / True = the host
+    writes them into device memory where the device allows it (the default), False = a pinned host slot the kernel reads
+    across the bus.  Returns whether the push is available on the current device.  Same packets either way."""
+    rc = int(_lib.lib().rd_set_input_push(-1 if on is None else (1 if on else 0)))
+    if rc < 0:
+        _lib.check(rc)
+    return rc == 1
 
 
 def search(quantized: np.ndarray, cfg: PacketConfig) -> List[int]:

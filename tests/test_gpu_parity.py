@@ -585,6 +585,50 @@ def test_complex_blocks_equal_the_reference_on_every_fixture_stream(dsp, golden_
     assert n >= len(golden_streams)
 
 
+def test_host_push_and_pinned_slot_give_the_same_packets(dsp, golden_streams):
+    """A copied block reaches the device either through an uncached device buffer the HOST writes (PCIe large BAR:
+    memcpy, sfence, HDP flush, launch) or through a pinned slot the kernel reads across the bus (rd_set_input_push).
+    On this pool the push is available and is the default: the test says so, then runs a fixture stream through both
+    forms, uint8 and complex128, synchronous and with two blocks in flight (the slot written again while the other
+    block's kernel runs), and 16 receivers in lock step - every block's packets against the real reference's lists."""
+    cfg = prod_cfg(dsp)
+    B, nb = 8192, synth.BLOCKS_PER_STREAM
+    lut = (np.arange(256, dtype=np.float64) - 127.4) / 127.6
+    try:
+        assert dsp.set_input_push(None), "this device does not offer the host push: the pinned slot serves (not an error, but say so)"
+        for push in (True, False):
+            dsp.set_input_push(push)
+            dem = dsp.Demodulator(cfg)
+            dem.demodulate(synth.synth_stream(0)[: 2 * B])
+            assert dem.input_pushed == push
+            for seed in (0, 21, 50):
+                raw = synth.synth_stream(seed)
+                want = dense_calls(golden_streams[str(seed)]["calls"], nb)
+                cplx = lut[raw[0::2]] + 1j * lut[raw[1::2]]
+                for blocks in ([raw[2 * B * b: 2 * B * (b + 1)] for b in range(nb)], [cplx[B * b: B * (b + 1)] for b in range(nb)]):
+                    dem.reset()
+                    assert_calls_equal([dem.demodulate(x) for x in blocks], want)
+                    dem.reset()
+                    got = []
+                    dem.submit(blocks[0])
+                    for x in blocks[1:]:
+                        dem.submit(x)
+                        got.append(dem.fetch())
+                    got.append(dem.fetch())
+                    assert_calls_equal(got, want)
+            seeds = list(range(16))
+            raws = synth.synth_streams(seeds)
+            md = dsp.MultiDemodulator(cfg, len(seeds))
+            per = [[] for _ in seeds]
+            for b in range(nb):
+                for i, pk in enumerate(md.demodulate(raws[:, 2 * B * b: 2 * B * (b + 1)])):
+                    per[i].append(pk)
+            for i, seed in enumerate(seeds):
+                assert_calls_equal(per[i], dense_calls(golden_streams[str(seed)]["calls"], nb))
+    finally:
+        dsp.set_input_push(None)
+
+
 def test_submit_fetch_pipeline_equals_synchronous_path(dsp, golden_streams):
     """rd_demod_submit / rd_demod_fetch with two blocks in flight over a 33-block stream: the same
     packets (index, bytes, order, RSSI/SNR) as demodulate() block by block, and as the reference."""
