@@ -936,6 +936,8 @@ static hsa_status_t rd_hdp_cb(hsa_agent_t agent, void *data) {
 static int g_push_mode = -1;   // rd_set_input_push: 0 = never
 static bool push_available(int dev) {
     if (dev < 0 || dev >= RD_MAX_DEVICES || g_push_mode == 0) return false;
+    static std::mutex mu;   // (handles may be created from several threads)
+    std::lock_guard<std::mutex> lock(mu);
     rd_push_info &p = g_push[dev];
     if (p.state) return p.state > 0;
     p.state = -1;
