@@ -207,6 +207,19 @@ def test_soak_small_configs_dense_duplicates(dsp, batchmod):
     assert n >= 768 and at_edge >= 5
 
 
+def test_soak_streaming_one_launch_forms(dsp):
+    """tools/soak_stream.py, 120 cases: the Davis configuration at seven block sizes (one to four workgroups per
+    complex block, ragged pieces), bursts at random positions, amplitudes and offsets or degenerate inputs, blocks as
+    uint8 / complex128 / uint8 then complex128, synchronous or two in flight, pushed by the host or read from the pinned
+    slot: every call's packets and the final window against the C oracle (dsp.py:139-246)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rd_soak_stream", os.path.join(root, "tools", "soak_stream.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.soak(120, 11, verbose=False) > 100
+
+
 def test_batch_api_call_orders(dsp, batchmod, golden_streams):
     """run twice before fetching, results fetched twice, parse switched on between runs: the
     packets are those of the reference every time (counter sets alternate per run; records of a
