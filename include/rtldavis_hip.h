@@ -132,9 +132,9 @@ int rd_demod_blocks(rd_demod *h, const uint8_t *iq, size_t nbytes, rd_packet *ou
 /*
  * The same call split in two, for a receiver loop that must not wait (replaces the hop
  * runners/rtlsdr.py:100-103 `data_queue.put(samples)` -> worker.py:34-50 `demodulate(samples)`):
- * rd_demod_submit copies the block(s) into a pinned slot, starts the host-to-device copy on a copy stream
- * and queues the kernels behind it on the compute stream, then returns; rd_demod_fetch waits (polling) for
- * the OLDEST submitted block and returns its packets exactly as rd_demod_block / rd_demod_blocks would.
+ * rd_demod_submit copies the block(s) to where the device takes them from (see rd_set_input_push below; the multi-launch
+ * form: a pinned slot and a host-to-device copy on a copy stream) and queues the kernels, then returns; rd_demod_fetch
+ * waits (polling) for the OLDEST submitted block and returns its packets exactly as rd_demod_block / rd_demod_blocks would.
  * Two blocks may be in flight (RD_ERR_STATE on a third submit): block i+1's copy overlaps block i's
  * kernels.  count: 2 * block_size * n_streams bytes, or block_size complex128 samples (single stream).
  * The state mirrors below need a quiet handle (everything fetched).
