@@ -127,7 +127,9 @@ void rd_launch_window_update(uint32_t *win_out, const uint32_t *win_in, long n_w
 // The streaming handle's one-launch block (k_stream_block, rd_kernels.hip): everything of one demodulate() call - ring
 // roll, exact bits, window, search, slice + RSSI, results into mapped host memory - for NS streams in lock step.
 #define RD_SB_THREADS 1024
+#ifndef RD_SBC_THREADS
 #define RD_SBC_THREADS 256   // k_stream_block_cplx: a workgroup takes 8 x this many samples of the block
+#endif
 struct rd_sb_args {
     rd_devcfg cfg;
     uint8_t *ring;            // the streams' raw rings: [hdr 32 B][previous block][newest block], ring_stride apart
