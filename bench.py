@@ -170,6 +170,54 @@ def _cpu_model():
     return "unknown cpu"
 
 
+class ChipSampler:
+    """Package power and shader clock as the chip reports them (rocm-smi, an ordinary user may read them) while the
+    sustained leg runs: a thread of its own, a sample per second from second 1.5 on, nothing if the tool is missing or
+    slow.  DESIGN 5.1: the run sits on the package's power cap - a number the reader should not have to take on trust."""
+
+    def __init__(self, device: int):
+        import threading
+        self.device, self.samples, self.cap, self._stop = device, [], None, threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _smi(self, *flags):
+        import subprocess
+        return subprocess.run(["rocm-smi", *flags, "-d", str(self.device)], capture_output=True, text=True, timeout=5).stdout
+
+    def _run(self):
+        import re
+        try:
+            if self._stop.wait(1.5):
+                return
+            while not self._stop.is_set() and len(self.samples) < 8:
+                out = self._smi("--showpower", "--showclocks")
+                pw = re.search(r"Power \(W\): ([0-9.]+)", out)
+                ck = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+                if pw:
+                    self.samples.append((float(pw.group(1)), int(ck.group(1)) if ck else None))
+                if self._stop.wait(1.0):
+                    break
+            m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", self._smi("--showmaxpower"))
+            self.cap = float(m.group(1)) if m else None
+        except Exception:
+            pass
+
+    def stop(self) -> dict:
+        self._stop.set()
+        self._t.join(timeout=8)
+        if not self.samples:
+            return {}
+        pw = [p for p, _ in self.samples]
+        ck = [c for _, c in self.samples if c is not None]
+        out = {"package_power_W": [min(pw), max(pw)], "power_samples": len(pw)}
+        if ck:
+            out["sclk_MHz"] = [min(ck), max(ck)]
+        if self.cap:
+            out["power_cap_W"] = self.cap
+        return out
+
+
 def wideband(args):
     """configs[2]: one step = channelize one second of wideband capture into the batch demodulator's
     input, demodulate the 51 channels, fetch the packets.  Parity here is end to end (every injected
@@ -461,6 +509,7 @@ def main():
         k = max(10, int(args.sustain / max(elapsed / args.steps, 1e-4)))
         for x in bds:
             x.timing()
+        chip = ChipSampler(local_rank) if args.sustain >= 3 else None   # (what the chip reports meanwhile: rocm-smi, own thread)
         t1 = time.perf_counter()
         run_steps(k)
         sync_all()
@@ -470,6 +519,8 @@ def main():
         sustained = {"seconds": round(dt_s, 2), "steps": k, "value": round(n_streams * n_samples * k / dt_s / 1e6, 1),
                      "unit": "MS/s", "ms_per_step": round(1e3 * dt_s / k, 4), "kernel_ms": round(float(dm2), 4),
                      "roofline_frac": round(n_streams * n_samples * 2 / (dm2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if chip is not None:
+            sustained.update(chip.stop())
 
     # ---- host-fed leg (never `value`): every step's input crosses the bus.  upload(i + 1) is issued on a copy stream
     # while run(i) computes (rd_batch_upload_async: the run waits for its upload on the device, the upload for the
