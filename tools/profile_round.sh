@@ -48,6 +48,8 @@ python3 $ROOT/tools/profile_collect.py stats $OUT/trace_wb $OUT wideband_ | tee 
 
 step "7/9 streaming handle: uint8 and complex input, the multi-launch form, the worker's queue hop against the ring"
 timeout -k 10 200 python3 $ROOT/tools/stream_latency.py > $OUT/stream_latency.txt 2>&1
+echo "== RD_PUSH_INPUT=0 (the pinned slot, read by the kernel across the bus)" >> $OUT/stream_latency.txt
+RD_PUSH_INPUT=0 timeout -k 10 200 python3 $ROOT/tools/stream_latency.py 2>&1 | grep -E "complex|^demodulate|^submit|16 receivers" >> $OUT/stream_latency.txt
 echo "== RD_STREAM_IMPL=legacy" >> $OUT/stream_latency.txt
 RD_STREAM_IMPL=legacy timeout -k 10 200 python3 $ROOT/tools/stream_latency.py 2>&1 | grep -E "complex|^demodulate" >> $OUT/stream_latency.txt
 echo "== worker: queue hop against the shared-memory ring (tools/worker_rate.py)" >> $OUT/stream_latency.txt
