@@ -306,6 +306,8 @@ void rd_debug_mfma_taps(uint16_t *out);
 /* The A operand of the 8-output formulation (rd_mfma.h, RD_OPT_B8): uint16 [2 k-steps][64 lanes][8 elements]; a row of
  * the 32-row tile is one digit of one component of one of 8 outputs. */
 void rd_debug_mfma_taps8(uint16_t *out);
+/* the same matrix compressed for the 2:4-sparse matrix instruction: vals[64][8] f16 bit patterns, idx[64] (rd_mfma.h) */
+void rd_debug_mfma_taps8s(uint16_t *vals, uint32_t *idx);
 /* Run k_demod_mfma alone on host data: g_out float [n_streams * tiles][2048][2] (kernel units),
  * bits_out the packed signs BEFORE the exact fix-up (words per stream = ceil(n_samples / 32)),
  * fix_out / n_fix the fix-up list it produced ((word index << 4) | group mask).  hist_mode: every

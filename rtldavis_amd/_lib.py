@@ -102,6 +102,7 @@ SIGNATURES = {
     "rd_chan_run_host": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
     "rd_debug_mfma_taps": (None, [_P]),
     "rd_debug_mfma_taps8": (None, [_P]),
+    "rd_debug_mfma_taps8s": (None, [_P, _P]),
     "rd_debug_demod_mfma": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_int, C.c_uint32, _P, _P, _P, C.c_uint32,
                                       C.POINTER(C.c_uint32)]),
 }

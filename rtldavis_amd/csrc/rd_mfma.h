@@ -188,3 +188,57 @@ constexpr rd_mf_taps8 rd_mf_make_taps8() {
             }
     return t;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same tile on the 2:4-SPARSE matrix instruction (v_smfmac_f32_32x32x32_f16: K = 32 in the time of a dense K = 16).
+// A real tap times j^n touches EITHER the I or the Q byte of a sample, never both, and a group of four consecutive
+// elements of a k-step is (I_a, I_b, Q_a, Q_b) of two neighbouring samples (RD_MF_ELEM): at most two of the four are
+// non-zero in any row - the A matrix is 2:4 sparse by construction, and a block's two k-steps become ONE instruction.
+// Operand layout (tools/ubench/smfmac_layout.hip, found by trying hypotheses against the instruction):
+//   B  lane (n, h), element i:      i < 8 -> K = 8 h + i (the first k-step's bytes of this lane half),
+//                                   i >= 8 -> K = 16 + 8 h + (i - 8) (the second k-step's) = the two dense B fragments
+//   A  lane (R, s), element i:      compressed slot of k-step s, group j = i / 2 (K = 16 s + 4 j .. + 3), its first (i even)
+//                                   or second (i odd) kept element; position in the group = bits [2 i + 1 : 2 i] of idx
+//   D  as the dense instruction.
+// A kept element's value may be zero (a group with fewer than two taps): positions are then filled in ascending order.
+struct alignas(16) rd_mf_taps8s {
+    uint16_t v[64][8];   // [lane][compressed element] as f16 bit patterns
+    uint32_t idx[64];    // [lane] sixteen bits: two per element
+};
+
+constexpr rd_mf_taps8s rd_mf_make_taps8s(bool *ok) {
+    rd_mf_taps8s t = {};
+    *ok = true;
+    for (int lane = 0; lane < 64; lane++) {
+        const int R = lane & 31, s = lane >> 5;
+        uint32_t idx = 0;
+        for (int j = 0; j < 4; j++) {              // group j of k-step s
+            int pos[2] = {-1, -1}, val[2] = {0, 0}, n = 0;
+            for (int q = 0; q < 4; q++) {          // dense element kk = 4 j + q of the k-step: lane half kk / 8, element kk % 8
+                const int kk = 4 * j + q;
+                const int w = 16 * s + 8 * (kk >> 3) + RD_MF_ELEM(kk & 7);
+                int dig = 0;
+                const int c = rd_mf8_coef(R, w, &dig);
+                const int a = c < 0 ? -c : c;
+                const int hi = (a + 1024) >> 11, lo = a - hi * 2048;
+                const int v = c < 0 ? -(dig == 0 ? hi : lo) : (dig == 0 ? hi : lo);
+                if (v != 0) {
+                    if (n < 2) { pos[n] = q; val[n] = v; }
+                    n++;
+                }
+            }
+            if (n > 2) *ok = false;
+            // fill up with zero-valued elements, positions ascending and distinct
+            if (n == 0) { pos[0] = 0; pos[1] = 1; }
+            else if (n == 1) {
+                if (pos[0] < 3) { pos[1] = pos[0] + 1; val[1] = 0; }
+                else { pos[1] = pos[0]; val[1] = val[0]; pos[0] = 2; val[0] = 0; }
+            }
+            t.v[lane][2 * j] = rd_mf_f16_of_int(val[0]);
+            t.v[lane][2 * j + 1] = rd_mf_f16_of_int(val[1]);
+            idx |= (uint32_t)(pos[0] | (pos[1] << 2)) << (4 * j);
+        }
+        t.idx[lane] = idx;
+    }
+    return t;
+}

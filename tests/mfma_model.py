@@ -129,6 +129,28 @@ def taps8_from_lib() -> np.ndarray:
     return raw.view(np.float16).astype(np.float64).reshape(2, 64, 8)
 
 
+def taps8_sparse_from_lib() -> np.ndarray:
+    """The tap matrix of the 8-output formulation as the kernel hands it to the 2:4-sparse matrix instruction
+    (v_smfmac_f32_32x32x32_f16; rd_mfma.h: rd_mf_taps8s), expanded to the dense [32 rows][32 K] matrix by the instruction's
+    operand layout (tools/ubench/smfmac_layout.hip): lane (R, s), compressed element i -> K = 16 s + 4 (i // 2) + position,
+    position = bits [2 i + 1 : 2 i] of the lane's index word; K = 16 s + 8 h + e is element e of lane half h of k-step s."""
+    from rtldavis_amd import _lib
+    vals = np.zeros(64 * 8, dtype=np.uint16)
+    idx = np.zeros(64, dtype=np.uint32)
+    _lib.lib().rd_debug_mfma_taps8s(vals.ctypes.data, idx.ctypes.data)
+    v = vals.view(np.float16).astype(np.float64).reshape(64, 8)
+    dense = np.zeros((32, 32))
+    for lane in range(64):
+        R, s = lane & 31, lane >> 5
+        assert idx[lane] >> 16 == 0
+        for j in range(4):
+            p0, p1 = (int(idx[lane]) >> (4 * j)) & 3, (int(idx[lane]) >> (4 * j + 2)) & 3
+            assert p0 < p1, "positions of a group ascending and distinct"
+            dense[R, 16 * s + 4 * j + p0] += v[lane, 2 * j]
+            dense[R, 16 * s + 4 * j + p1] += v[lane, 2 * j + 1]
+    return dense
+
+
 def model_tile8(win: np.ndarray, taps8: np.ndarray) -> np.ndarray:
     """One tile through the B8 lane maps: lane (n, h), block b = 0..7 holds - in registers 2 r' + comp (hi digit) and
     8 + 2 r' + comp (lo digit) - output t = 64 n + 8 b + 4 h + 1 + r', r' = 0..3.  Block b's window = chunks b, b + 1

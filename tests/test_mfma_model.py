@@ -139,3 +139,20 @@ def test_b8_lane_maps_reproduce_the_direct_filter():
         got = M.model_tile8(raw, taps8)
         want = M.g_direct(raw[16:], np.concatenate([np.full(2, 127, np.uint8), raw[:16]]))
         assert np.array_equal(got, want[1: M.TILE + 1]), trial
+
+
+def test_sparse_tap_matrix_is_the_dense_one():
+    """The kernel issues ONE 2:4-sparse matrix instruction per block where the dense formulation has two: the compressed
+    taps + positions the library hands it (rd_debug_mfma_taps8s), expanded by the instruction's operand layout, are the
+    dense 32 x 32 tap matrix of rd_debug_mfma_taps8 element for element - so everything test_b8_* says about that
+    matrix (digits exact in f16, row sums below 2^24, the nine taps of every output) holds for what the kernel runs."""
+    taps8 = M.taps8_from_lib()
+    dense = np.zeros((32, 32))
+    for d in range(2):
+        for lane in range(64):
+            dense[lane & 31, 16 * d + 8 * (lane >> 5): 16 * d + 8 * (lane >> 5) + 8] = taps8[d, lane]
+    sparse = M.taps8_sparse_from_lib()
+    assert np.array_equal(sparse, dense)
+    # 2:4: no group of four consecutive K of any row holds more than two taps
+    assert (np.count_nonzero(dense.reshape(32, 8, 4), axis=2) <= 2).all()
+
