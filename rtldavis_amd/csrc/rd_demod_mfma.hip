@@ -62,9 +62,10 @@ static const rd_mf_taps h_mf_taps = rd_mf_make_taps();   // (the 16-output tap m
 __device__ const rd_mf_taps8 g_mf_taps8 = rd_mf_make_taps8();
 static const rd_mf_taps8 h_mf_taps8 = rd_mf_make_taps8();
 extern "C" void rd_debug_mfma_taps8(uint16_t *out) { memcpy(out, &h_mf_taps8, sizeof h_mf_taps8); }
-// the same tap matrix compressed for the 2:4-sparse instruction (rd_mfma.h); RD_MF_SPARSE=0 builds the dense pair instead
+// the same tap matrix compressed for the 2:4-sparse instruction (rd_mfma.h): what the kernel issues; -DRD_MF_SPARSE=0
+// (`make dense`) builds the pair of dense instructions of round 3 instead - same results, 1.5 % slower at the power cap
 #ifndef RD_MF_SPARSE
-#define RD_MF_SPARSE 0
+#define RD_MF_SPARSE 1
 #endif
 constexpr bool rd_mf_taps8s_ok() { bool ok = true; (void)rd_mf_make_taps8s(&ok); return ok; }
 static_assert(rd_mf_taps8s_ok(), "a row of the tap matrix has more than two non-zero elements in a group of four");
@@ -194,10 +195,18 @@ __device__ __forceinline__ void rd_mf8_finish(const rd_mf8_kept &k, rd_f4v &p, u
 }
 
 template <int B, int DBG>
-__device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v &dcC, const int sidx, const rd_u2v (&D)[9], rd_h8 &bfA,
-                                             const rd_mf8_addr &ad, rd_mf8_kept &k0, rd_mf8_kept &kp, rd_f4v &p, uint32_t &Wlo,
+__device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v &dcC, const int sidx, const int sidx2, const rd_u2v (&D)[9],
+                                             rd_h8 &bfA, rd_h16 &bb, const rd_mf8_addr &ad, rd_mf8_kept &k0, rd_mf8_kept &kp, rd_f4v &p, uint32_t &Wlo,
                                              uint32_t &Whi, uint32_t &fblo, uint32_t &fbhi, bool &slow, float *dg, int dleft) {
     const rd_h8 bfB = rd_mf_frag(D[B + 1]);
+    if (RD_MF_SPARSE && DBG != 8 && DBG != 9) {
+        // the 16-element B operand lives in eight registers for the whole tile; the new fragment goes into the half the
+        // fragment of two blocks ago occupies - even blocks read (F_b, F_b+1), odd blocks (F_b+1, F_b) with the taps of
+        // the two k-steps swapped (A[1], sidx2): no register-to-register move
+        const rd_h16 wB = __builtin_shufflevector(bfB, bfB, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (B & 1) bb = __builtin_shufflevector(wB, bb, 0, 1, 2, 3, 4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31);
+        else bb = __builtin_shufflevector(bb, wB, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
+    }
     __builtin_amdgcn_sched_barrier(0);
     rd_f16v acc;
     if (DBG == 8 || DBG == 9) {
@@ -211,15 +220,19 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
     } else if (RD_MF_SPARSE) {
         // ONE 2:4-sparse instruction for the block's two k-steps (A[0] = the compressed taps, sidx their positions).  It
         // accumulates in place: the accumulators start as a copy of the constant C tuple (-D_hi in the hi rows)
-        const rd_h16 bb = __builtin_shufflevector(bfA, bfB, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-        // (-D_hi in the hi rows, 0 in the lo rows, written from two scalars per block: a constant 16-register tuple kept
-        // for the whole kernel - what the dense pair's C operand is - does not fit beside the rest any more)
-        float dh = -(float)RD_MF_DHI / 16777216.0f, zz = 0.0f;
-        asm volatile("" : "+s"(dh), "+s"(zz));
-        rd_f16v c0;
+        // (-D_hi in the hi rows, 0 in the lo rows, written per block from a scalar pair - eight 64-bit moves: a constant
+        // 16-register tuple kept for the whole kernel, what the dense pair's C operand is, does not fit beside the rest)
+        const uint32_t dbits = __builtin_bit_cast(uint32_t, -(float)RD_MF_DHI / 16777216.0f);
+        uint64_t dh2 = ((uint64_t)dbits << 32) | dbits;
+        asm volatile("" : "+s"(dh2));
+        struct { uint64_t q[8]; } ci;
 #pragma unroll
-        for (int i = 0; i < 16; i++) c0[i] = i < 8 ? dh : zz;
-        acc = __builtin_amdgcn_smfmac_f32_32x32x32_f16(A[0], bb, c0, sidx, 0, 0);
+        for (int i = 0; i < 4; i++) asm volatile("v_mov_b64 %0, %1" : "=v"(ci.q[i]) : "s"(dh2));
+#pragma unroll
+        for (int i = 4; i < 8; i++) asm volatile("v_mov_b64 %0, 0" : "=v"(ci.q[i]));
+        const rd_f16v c0 = __builtin_bit_cast(rd_f16v, ci);
+        acc = (B & 1) ? __builtin_amdgcn_smfmac_f32_32x32x32_f16(A[1], bb, c0, sidx2, 0, 0)
+                      : __builtin_amdgcn_smfmac_f32_32x32x32_f16(A[0], bb, c0, sidx, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], bfA, dcC, 0, 0, 0);  // C: -D_hi in the hi rows
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], bfB, acc, 0, 0, 0);
@@ -256,21 +269,23 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
 
 // One tile: `word` = word h of column n (final), `fbw` = its flag bytes (byte k != 0: group k inside the guard band).
 template <int DBG>
-__device__ __forceinline__ void rd_mf8_tile(const rd_h8 (&A)[2], const rd_f16v &dcC, const int sidx, const rd_u2v (&D)[9], const rd_mf8_addr &ad,
+__device__ __forceinline__ void rd_mf8_tile(const rd_h8 (&A)[2], const rd_f16v &dcC, const int sidx, const int sidx2, const rd_u2v (&D)[9],
+                                            const rd_mf8_addr &ad,
                                             uint32_t &word, uint32_t &fbw, bool &slow, float *dg, int dleft) {
     rd_h8 bfA = rd_mf_frag(D[0]);
+    rd_h16 bb = __builtin_shufflevector(bfA, bfA, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);   // (the low half counts)
     rd_mf8_kept k0, kp;
     rd_f4v p = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t Wlo = 0, Whi = 0, fblo = 0, fbhi = 0;
     slow = false;
-    rd_mf8_block<0, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<1, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<2, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<3, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<4, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<5, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<6, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
-    rd_mf8_block<7, DBG>(A, dcC, sidx, D, bfA, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<0, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<1, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<2, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<3, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<4, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<5, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<6, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
+    rd_mf8_block<7, DBG>(A, dcC, sidx, sidx2, D, bfA, bb, ad, k0, kp, p, Wlo, Whi, fblo, fbhi, slow, dg, dleft);
     // block 0's predecessors (the previous column's block 7, this column's half 0, or the carry) together with block 7's
     rd_f4v p0 = rd_lds_read16<0>(ad.rd0);
     rd_mf8_finish<7, DBG>(kp, p, Whi, fbhi, slow);  // (its wait covers both reads)
@@ -508,11 +523,14 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     // lo-digit rows: 16 registers) for the whole kernel
     rd_h8 A8[2];
     rd_f16v dcC;
-    int sidx = 0;
+    int sidx = 0, sidx2 = 0;
     if (RD_MF_SPARSE && DBG != 8 && DBG != 9) {
+        // (the compressed taps of this lane's k-step, and - for the odd blocks, whose B operand holds the two k-steps the
+        // other way round - of the other one: the other lane half's)
         A8[0] = *(const rd_h8 *)g_mf_taps8s.v[lane];
-        A8[1] = A8[0];
+        A8[1] = *(const rd_h8 *)g_mf_taps8s.v[lane ^ 32];
         sidx = (int)g_mf_taps8s.idx[lane];
+        sidx2 = (int)g_mf_taps8s.idx[lane ^ 32];
     } else {
         A8[0] = *(const rd_h8 *)g_mf_taps8.v[0][lane];
         A8[1] = *(const rd_h8 *)g_mf_taps8.v[1][lane];
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
     // opaque: sixteen registers for the whole kernel, not sixteen v_mov in front of every block - and a use in front
     // of the loop: the wait for the tap loads must not end up inside it, where it would be a vmcnt(0) that also drains
     // the prefetched tile in every iteration
-    if (RD_MF_SPARSE && DBG != 8 && DBG != 9) asm volatile("" : "+v"(A8[0]), "+v"(sidx));
+    if (RD_MF_SPARSE && DBG != 8 && DBG != 9) asm volatile("" : "+v"(A8[0]), "+v"(A8[1]), "+v"(sidx), "+v"(sidx2));
     else asm volatile("" : "+v"(A8[0]), "+v"(A8[1]), "+v"(dcC));
     // window addresses in the image
     const uint32_t img_addr = rd_lds_addr(img0);
@@ -650,7 +668,7 @@ __global__ __launch_bounds__(RD_MF_WG, RD_MF_MINWAVES) void k_demod_mfma(rd_layo
         } else {
             float *dg = DBG == 3 ? dbg_g + ((size_t)tile * RD_TILE_SAMPLES + 64 * n + 4 * h + 1) * 2 : nullptr;
             const int dleft = RD_TILE_SAMPLES - (64 * n + 4 * h + 1);
-            rd_mf8_tile<DBG>(A8, dcC, sidx, D, ad8, word, fbw8, slow_taken, dg, dleft);
+            rd_mf8_tile<DBG>(A8, dcC, sidx, sidx2, D, ad8, word, fbw8, slow_taken, dg, dleft);
             ad8.rd0 ^= rtoggle;
             ad8.xw7 ^= wtoggle;
         }

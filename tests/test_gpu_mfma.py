@@ -123,23 +123,22 @@ def test_degenerate_input_is_flagged_not_wrong():
     check(streams)
 
 
-def test_sparse_matrix_instruction_build_is_bit_exact_too():
-    """`make -C rtldavis_amd/csrc sparse` builds the demod kernel with ONE 2:4-sparse v_smfmac_f32_32x32x32_f16 per block
-    where the product has two dense v_mfma_f32_32x32x16_f16 (rd_mfma.h: the tap rows are 2:4 sparse by construction).  It
-    is no faster (profiles/r04_sparse_mfma.txt) and therefore not the product, but it is the same arithmetic: this file's
-    raw-pipe-output checks and the batch parity tests run on that library in a child process (the library is chosen at
-    load time).  Skipped when the library has not been built."""
+def test_dense_matrix_instruction_build_is_bit_exact_too():
+    """The product issues ONE 2:4-sparse v_smfmac_f32_32x32x32_f16 per block (rd_mfma.h: the tap rows are 2:4 sparse by
+    construction); `make -C rtldavis_amd/csrc dense` builds round 3's pair of dense v_mfma_f32_32x32x16_f16 instead
+    (1.5 % slower at the power cap: profiles/r04_sparse_mfma.txt).  Same arithmetic: this file's raw-pipe-output checks
+    and the batch parity tests run on that library in a child process (the library is chosen at load time).  Skipped when
+    the library has not been built."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "rtldavis_amd", "librtldavis_hip_sparse.so")
+    lib = os.path.join(root, "rtldavis_amd", "librtldavis_hip_dense.so")
     if not os.path.exists(lib):
-        pytest.skip("librtldavis_hip_sparse.so not built (make -C rtldavis_amd/csrc sparse)")
+        pytest.skip("librtldavis_hip_dense.so not built (make -C rtldavis_amd/csrc dense)")
     env = dict(os.environ, RTLDAVIS_HIP_LIB=lib)
-    sel = "not sparse_matrix_instruction and (mfma or pipe or golden or batch or near or degenerate or startup or soak_small)"
+    sel = "not dense_matrix_instruction and (mfma or pipe or golden or batch or near or degenerate or startup or soak_small)"
     out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider",
                           os.path.join(root, "tests", "test_gpu_mfma.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
     tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:]
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
     assert " passed" in tail and "failed" not in tail, tail
-

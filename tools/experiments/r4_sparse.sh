@@ -1,6 +1,6 @@
 #!/bin/bash
-# the demod kernel on the 2:4-sparse matrix instruction (the tree) against the dense pair (librtldavis_hip_dense.so,
-# -DRD_MF_SPARSE=0): the matrix-pipe tests and the whole GPU suite on the tree, then three interleaved rounds of the bench
+# the demod kernel on the 2:4-sparse matrix instruction (the tree) against the dense pair (librtldavis_hip_dense.so, make dense):
+# the whole GPU suite (the dense build is one of its tests), then three interleaved rounds of the bench
 set -e
 mkdir -p gpurun_out/r4sparse
 timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r4sparse/tests.log 2>&1 || { tail -40 gpurun_out/r4sparse/tests.log; exit 1; }
