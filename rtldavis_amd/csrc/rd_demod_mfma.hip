@@ -225,6 +225,7 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
         const uint32_t dbits = __builtin_bit_cast(uint32_t, -(float)RD_MF_DHI / 16777216.0f);
         uint64_t dh2 = ((uint64_t)dbits << 32) | dbits;
         asm volatile("" : "+s"(dh2));
+        // (sixteen v_mov_b32 and eight v_pk_mov_b32 measured 0.3 and 1.7 % slower: gpurun r4 ab i32 / i2)
         struct { uint64_t q[8]; } ci;
 #pragma unroll
         for (int i = 0; i < 4; i++) asm volatile("v_mov_b64 %0, %1" : "=v"(ci.q[i]) : "s"(dh2));

@@ -135,7 +135,8 @@ def test_dense_matrix_instruction_build_is_bit_exact_too():
     if not os.path.exists(lib):
         pytest.skip("librtldavis_hip_dense.so not built (make -C rtldavis_amd/csrc dense)")
     env = dict(os.environ, RTLDAVIS_HIP_LIB=lib)
-    sel = "not dense_matrix_instruction and (mfma or pipe or golden or batch or near or degenerate or startup or soak_small)"
+    sel = ("not dense_matrix_instruction and (matrix_pipe or synthetic_bursts or ragged_tail or degenerate or test_batch_ or "
+           "random_configs or soak_small or full_size or startup or one_launch_tail or long_streams)")
     out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider",
                           os.path.join(root, "tests", "test_gpu_mfma.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
