@@ -818,12 +818,14 @@ static void rd_mf_launch_variant(const rd_mf_launch_args &a) {
     }();
     // (three workgroups per CU instead of the four that fit: 4 % slower)
     const int per_cu = (P.per_cu_env >= 1 && P.per_cu_env <= 8) ? P.per_cu_env : per_cu_occ;
-    // Tiles per chunk: a multiple of the 4-tile store groups.  With the work queues (default) 16: the chunks past a
-    // wave's first are handed out on demand, the waves that run faster take more of them, and shorter chunks
-    // even the finish out (0.459 ms; 28: 0.471, 12: 0.466, 8: 0.465 but a longer fix-up list).  With equal shares
-    // (RD_K1_STFLAGS & 4096) 28, the best of a sweep from 8 to 66 on 4096 x 132 tiles (profiles/r02_chunk_sweep.txt).
+    // Tiles per chunk: a multiple of the 4-tile store groups.  With the work queues (default) 8: the chunks past a
+    // wave's first are handed out on demand, the waves that run faster take more of them, and shorter chunks even the
+    // finish out.  With the sparse-instruction kernel, three interleaved rounds on two boxes (profiles/r04_chunk.txt):
+    // 8: 0.434-0.445 ms, 10: 0.437, 6: 0.436, 16 (the default until then): 0.451-0.455, 12: 0.455, 4: 0.441; the
+    // fix-up list grows (a chunk's first group is always listed: 0.23 % of the runs against 0.13 %) and k_tail with it by
+    // 4 us - the step is 1 % shorter.  With equal shares (RD_K1_STFLAGS & 4096) 28 (profiles/r02_chunk_sweep.txt).
     // A small workload gets shorter chunks, down to one store group, until every resident wave has one.
-    uint32_t chunk = P.chunk_env > 0 ? (uint32_t)P.chunk_env : ((P.stflags & 4096) ? 28 : 16);
+    uint32_t chunk = P.chunk_env > 0 ? (uint32_t)P.chunk_env : ((P.stflags & 4096) ? 28 : 8);
     if (P.chunk_env <= 0) {
         const uint64_t waves = (uint64_t)P.n_cu * per_cu * RD_MF_WAVES;
         while (chunk > RD_MF_STAGE_TILES && a.total64 / chunk < waves) chunk -= RD_MF_STAGE_TILES;
