@@ -231,6 +231,9 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
         for (int i = 0; i < 4; i++) asm volatile("v_mov_b64 %0, %1" : "=v"(ci.q[i]) : "s"(dh2));
 #pragma unroll
         for (int i = 4; i < 8; i++) asm volatile("v_mov_b64 %0, 0" : "=v"(ci.q[i]));
+        // (a vector write of a register the matrix instruction reads as its accumulator needs two wait states in between;
+        // the compiler's hazard recognizer does not look into the asm statements above)
+        asm volatile("s_nop 1" ::: "memory");
         const rd_f16v c0 = __builtin_bit_cast(rd_f16v, ci);
         acc = (B & 1) ? __builtin_amdgcn_smfmac_f32_32x32x32_f16(A[1], bb, c0, sidx2, 0, 0)
                       : __builtin_amdgcn_smfmac_f32_32x32x32_f16(A[0], bb, c0, sidx, 0, 0);
