@@ -13,8 +13,8 @@ raw = synth.synth_stream(0)
 blocks = [raw[2 * B * b: 2 * B * (b + 1)] for b in range(33)]
 cblocks = [((b[0::2].astype(np.float64) - 127.5) / 127.5 + 1j * (b[1::2].astype(np.float64) - 127.5) / 127.5) for b in blocks]
 PHASES = {
-    "uint8": ["loads issued (barrier)", "block over the link, ring + LDS stores", "exact sign bits", "window out + search", "slice, RSSI, flag"],
-    "complex128": ["workgroup 0: piece over the link, ring + LDS stores", "workgroup 0: signs (float64, from LDS)",
+    "uint8": ["loads issued (barrier)", "block in (device memory, or the link), ring + LDS stores", "exact sign bits", "window out + search", "slice, RSSI, flag"],
+    "complex128": ["workgroup 0: piece in (device memory, or the link), ring + LDS", "workgroup 0: signs (float64, from LDS)",
                    "workgroup 0: words out, stores acknowledged, counted in", "last workgroup: (arrival of the others,) window in",
                    "last workgroup: search", "last workgroup: slice, RSSI, flag"],
 }
