@@ -252,14 +252,15 @@ __device__ __forceinline__ void rd_mf8_block(const rd_h8 (&A)[2], const rd_f16v 
         for (int r = 0; r < 4; r++)  // the tile's last output (column 31, half 1, block 7, r' = 3) belongs to the next tile
             if (8 * B + r < dleft) { dg[2 * (8 * B + r)] = g[2 * r]; dg[2 * (8 * B + r) + 1] = g[2 * r + 1]; }
     }
-    if (DBG != 10) {   // (10 - WRONG results, timing only: without the predecessor exchange's LDS traffic)
+    if (DBG != 10 && DBG != 11) {   // (10, 11 - WRONG results, timing only: without the predecessor exchange's LDS traffic)
         const rd_f4v x = {g[4], g[5], g[6], g[7]};
         if (B == 7) rd_lds_write16<0>(ad.xw7, x);
         else rd_lds_write16<rd_mf8_woff<B>()>(ad.xw, x);
     } else {
         asm volatile("" : : "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]));
     }
-    if (B >= 1 && DBG != 10) p = rd_lds_read16<0>(B == 1 ? ad.rd1 : (B & 1) ? ad.rdO : ad.rdE);  // consumed one block later
+    if (B >= 1 && DBG != 10 && DBG != 11) p = rd_lds_read16<0>(B == 1 ? ad.rd1 : (B & 1) ? ad.rdO : ad.rdE);  // consumed one block later
+    if (DBG == 11) asm volatile("" : "+v"(p));   // (11: the predecessor's values unknown to the compiler - the finish's arithmetic stays, 10 folds it away)
     rd_mf8_kept &k = B == 0 ? k0 : kp;
     float t2, t3;
     k.n2 = rd_mf_num(g[0], g[1], g[2], g[3], t2);
@@ -894,6 +895,7 @@ bool rd_launch_demod_mfma(const rd_layout &lay, uint32_t *fix_list, uint32_t fix
             case 8: rd_mf_launch_variant<8, false>(a); return false;
             case 9: rd_mf_launch_variant<9, false>(a); return false;
             case 10: rd_mf_launch_variant<10, false>(a); return false;
+            case 11: rd_mf_launch_variant<11, false>(a); return false;
             default:
                 fprintf(stderr, "[rd diag] no kernel variant RD_K1_DEBUG=%d RD_K1_STAMPS=%d is compiled in\n", P.dbg, P.stamp);
                 abort();
